@@ -1,0 +1,47 @@
+# Builds the product library (HIP kernels + C ABI + C++ host mirror) for gfx950 and the CPU oracle.
+# hipcc cross-compiles without a GPU.  Strict floating point everywhere: no contraction, no fast-math,
+# correctly rounded f32 division and square root on the device.
+HIPCC   ?= /opt/rocm/bin/hipcc
+ARCH    ?= gfx950
+FPFLAGS := -ffp-contract=off -fno-fast-math
+DEVFLAGS:= --offload-arch=$(ARCH) -fhip-fp32-correctly-rounded-divide-sqrt
+CXXFLAGS:= -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wextra -Wno-unused-parameter $(FPFLAGS)
+
+LIB     := rrt_amd/librrt_amd.so
+OBJDIR  := build
+OBJS    := $(OBJDIR)/kernels.o $(OBJDIR)/capi.o $(OBJDIR)/scene_layout.o $(OBJDIR)/rrt.o $(OBJDIR)/host_capi.o
+
+all: $(LIB) oracle
+
+$(OBJDIR):
+	mkdir -p $(OBJDIR)
+
+$(OBJDIR)/kernels.o: rrt_amd/csrc/kernels.hip rrt_amd/csrc/kernels.h rrt_amd/csrc/scene_layout.h include/rrt_amd.h | $(OBJDIR)
+	$(HIPCC) $(CXXFLAGS) $(DEVFLAGS) -c $< -o $@
+
+$(OBJDIR)/capi.o: rrt_amd/csrc/capi.cpp rrt_amd/csrc/kernels.h rrt_amd/csrc/scene_layout.h include/rrt_amd.h | $(OBJDIR)
+	$(HIPCC) $(CXXFLAGS) -c $< -o $@
+
+$(OBJDIR)/scene_layout.o: rrt_amd/csrc/scene_layout.cpp rrt_amd/csrc/scene_layout.h include/rrt_amd.h | $(OBJDIR)
+	$(HIPCC) $(CXXFLAGS) -c $< -o $@
+
+$(OBJDIR)/rrt.o: rrt_amd/host/rrt.cpp rrt_amd/host/rrt.hpp include/rrt_amd.h | $(OBJDIR)
+	$(HIPCC) $(CXXFLAGS) -c $< -o $@
+
+$(OBJDIR)/host_capi.o: rrt_amd/host/host_capi.cpp rrt_amd/host/rrt.hpp include/rrt_amd.h include/rrt_amd_host.h | $(OBJDIR)
+	$(HIPCC) $(CXXFLAGS) -c $< -o $@
+
+$(LIB): $(OBJS)
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJS)
+
+oracle:
+	$(MAKE) -C oracle
+
+asm: rrt_amd/csrc/kernels.hip | $(OBJDIR)
+	$(HIPCC) $(CXXFLAGS) $(DEVFLAGS) -S --cuda-device-only -Rpass-analysis=kernel-resource-usage $< -o $(OBJDIR)/kernels.s
+
+clean:
+	rm -rf $(OBJDIR) $(LIB)
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle asm clean

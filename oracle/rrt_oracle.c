@@ -819,6 +819,9 @@ ORC_API orc_scene *orc_scene_from_arrays(uint32_t n, const float *c0x, const flo
     return s;
 }
 
+/* Scene::build_bvh (scene.rs:32-35) on a scene made from arrays; method 0 = Middle, 1 = EqualCount */
+ORC_API void orc_scene_build_bvh(orc_scene *s, int method) { scene_build_bvh(&s->sc, method); }
+
 ORC_API void orc_scene_free(orc_scene *s) { if (!s) return; free(s->sc.spheres); free(s->sc.nodes); free(s); }
 ORC_API uint32_t orc_scene_num_spheres(const orc_scene *s) { return s->sc.n_spheres; }
 ORC_API uint32_t orc_scene_num_nodes(const orc_scene *s) { return s->sc.n_nodes; }
@@ -966,6 +969,23 @@ ORC_API int orc_render(const orc_scene *s, uint32_t nx, uint32_t ny, uint32_t ns
     }
     free(J.thread_ctrs);
     return g_stack_overflow ? -1 : 0;
+}
+
+/* Chosen pixels only, per-sample mode: acc n x 3 floats (sums), rgb n x 3 bytes.  Lets a full-size
+ * image be spot-checked without rendering all of it on the CPU. */
+ORC_API void orc_render_pixels(const orc_scene *s, uint32_t nx, uint32_t ny, uint32_t ns, uint64_t seed, int max_depth,
+                               int pow5_mode, uint32_t n, const uint32_t *idx, float *acc, uint8_t *rgb, uint64_t *rays) {
+    opts_t O = {max_depth, pow5_mode};
+    ctrs_t C; memset(&C, 0, sizeof C);
+    for (uint32_t i = 0; i < n; i++) {
+        v4 c = v4_splat(0.0f);
+        for (uint32_t k = 0; k < ns; k++) {
+            xrng g; rng_seed_from_u64(&g, sample_stream_seed(seed, idx[i], k));
+            c = v4_add(c, pixel_sample(&s->sc, &s->cam, nx, ny, idx[i], &g, &C, &O));
+        }
+        pixel_finish(c, ns, rgb + (size_t)i * 3, acc + (size_t)i * 3);
+    }
+    if (rays) *rays = C.rays;
 }
 
 /* One path, for debugging and fine-grained parity: radiance of (pixel idx, sample k) in per-sample mode. */

@@ -1,0 +1,417 @@
+// C ABI of include/rrt_amd.h: context, scene upload and the wavefront render loop.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rrt_amd.h"
+#include "kernels.h"
+#include "scene_layout.h"
+
+using namespace rrt_amd;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) { g_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                                                       \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess) {                                                                             \
+            return fail(e_ == hipErrorOutOfMemory ? RRT_ERR_OUT_OF_MEMORY : RRT_ERR_HIP,                    \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                                 \
+        }                                                                                                   \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+constexpr uint32_t kDefaultSlots = 1u << 21;
+constexpr size_t kRadBudgetBytes = size_t(3) << 30;
+constexpr uint32_t kMaxBatchPaths = 1u << 30;
+constexpr uint32_t kChunk = 8;  // extend+shade rounds queued between two looks at the alive flag
+constexpr uint32_t kMaxDepthLimit = 4096;
+
+}  // namespace
+
+struct rrt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t prop{};
+    // scene
+    DevBuf nodes, sph, motion, motion_dt, sph_info, mat, prim_att;
+    SceneDev sd{};
+    bool has_scene = false, moving = false;
+    uint32_t n_spheres = 0, n_nodes = 0;
+    CameraDev cam{};
+    bool has_cam = false;
+    // path state
+    DevBuf rayA, rayB, rng, depth, hit, trail, queue, qcount, wave_stats, cursors, flags, stats_out;
+    DevBuf accum, rad, pixel_map, tmp_rgb, tmp_acc;
+    uint32_t *h_flags = nullptr;   // pinned
+    uint64_t *h_stats = nullptr;   // pinned
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> kev;   // event pairs around extend launches
+    // scratch for rrt_intersect
+    DevBuf q_org, q_dir, q_time, q_t, q_obj;
+};
+
+extern "C" {
+
+const char *rrt_last_error(void) { return g_err.c_str(); }
+const char *rrt_version(void) { return "rrt_amd 0.1 (gfx950)"; }
+
+int rrt_create(int device, rrt_ctx **out) {
+    if (!out) return fail(RRT_ERR_INVALID_ARGUMENT, "rrt_create: out is null");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(RRT_ERR_NO_DEVICE, "no HIP device available (there is no CPU fallback)");
+    if (device < 0) HIP_TRY(hipGetDevice(&device));
+    if (device >= n) return fail(RRT_ERR_INVALID_ARGUMENT, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    rrt_ctx *c = new rrt_ctx();
+    c->device = device;
+    if (hipGetDeviceProperties(&c->prop, device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **>(&c->h_flags), sizeof(uint32_t) * 64, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **>(&c->h_stats), sizeof(uint64_t) * kWaveStatWords, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        rrt_destroy(c);
+        return fail(RRT_ERR_HIP, "rrt_create: device set-up failed");
+    }
+    *out = c;
+    return RRT_OK;
+}
+
+void rrt_destroy(rrt_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (DevBuf *b : {&c->nodes, &c->sph, &c->motion, &c->motion_dt, &c->sph_info, &c->mat, &c->prim_att, &c->rayA, &c->rayB, &c->rng,
+                      &c->depth, &c->hit, &c->trail, &c->queue, &c->qcount, &c->wave_stats, &c->cursors, &c->flags, &c->stats_out,
+                      &c->accum, &c->rad, &c->pixel_map, &c->tmp_rgb, &c->tmp_acc, &c->q_org, &c->q_dir, &c->q_time, &c->q_t, &c->q_obj})
+        b->release();
+    for (hipEvent_t ev : c->kev) (void)hipEventDestroy(ev);
+    if (c->h_flags) (void)hipHostFree(c->h_flags);
+    if (c->h_stats) (void)hipHostFree(c->h_stats);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int rrt_device_info(rrt_ctx *c, char *name, size_t name_len, int *cus, uint64_t *hbm) {
+    if (!c) return fail(RRT_ERR_INVALID_ARGUMENT, "null context");
+    if (name && name_len) { std::snprintf(name, name_len, "%s (%s)", c->prop.name, c->prop.gcnArchName); }
+    if (cus) *cus = c->prop.multiProcessorCount;
+    if (hbm) *hbm = c->prop.totalGlobalMem;
+    return RRT_OK;
+}
+
+int rrt_upload_scene(rrt_ctx *c, const rrt_sphere_soa *sp, const rrt_material_soa *mt, const rrt_bvh_node *nodes, uint32_t n_nodes) {
+    if (!c) return fail(RRT_ERR_INVALID_ARGUMENT, "null context");
+    SceneLayout L;
+    std::string err;
+    int rc = build_scene_layout(sp, mt, nodes, n_nodes, L, err);
+    if (rc != RRT_OK) return fail(rc, err);
+    HIP_TRY(hipSetDevice(c->device));
+    c->has_scene = false;
+    auto up = [&](DevBuf &b, const void *src, size_t bytes) -> hipError_t {
+        hipError_t e = b.ensure(bytes ? bytes : 16);
+        if (e != hipSuccess) return e;
+        return bytes ? hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream) : hipSuccess;
+    };
+    HIP_TRY(up(c->nodes, L.nodes.data(), L.nodes.size() * 4));
+    HIP_TRY(up(c->sph, L.sph.data(), L.sph.size() * sizeof(Float4)));
+    HIP_TRY(up(c->motion, L.motion.data(), L.motion.size() * sizeof(Float4)));
+    HIP_TRY(up(c->motion_dt, L.motion_dt.data(), L.motion_dt.size() * 4));
+    HIP_TRY(up(c->sph_info, L.sph_info.data(), L.sph_info.size() * 4));
+    HIP_TRY(up(c->mat, L.mat.data(), L.mat.size() * sizeof(Float4)));
+    HIP_TRY(up(c->prim_att, L.prim_att.data(), L.prim_att.size() * sizeof(Float4)));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->sd.nodes = c->nodes.as<uint4>();
+    c->sd.root_ref = L.root_ref;
+    c->sd.sph = c->sph.as<float4>();
+    c->sd.motion = c->motion.as<float4>();
+    c->sd.motion_dt = c->motion_dt.as<float>();
+    c->sd.sph_info = c->sph_info.as<uint32_t>();
+    c->sd.mat = c->mat.as<float4>();
+    c->sd.prim_att = c->prim_att.as<float4>();
+    c->sd.flags = L.flags;
+    c->sd.u_time0 = L.u_time0;
+    c->sd.u_dt = L.u_dt;
+    c->moving = (L.flags & kSceneHasMoving) != 0;
+    c->n_spheres = L.n_spheres;
+    c->n_nodes = L.n_nodes;
+    c->has_scene = true;
+    return RRT_OK;
+}
+
+int rrt_set_camera(rrt_ctx *c, const rrt_camera *cam) {
+    if (!c || !cam) return fail(RRT_ERR_INVALID_ARGUMENT, "null argument");
+    if (!std::isfinite(cam->time_low) || !std::isfinite(cam->time_scale))
+        return fail(RRT_ERR_INVALID_ARGUMENT, "camera shutter times must be finite");
+    for (int k = 0; k < 3; k++) {
+        c->cam.llc[k] = cam->lower_left_corner[k]; c->cam.hor[k] = cam->horizontal[k]; c->cam.ver[k] = cam->vertical[k];
+        c->cam.org[k] = cam->origin[k]; c->cam.u[k] = cam->u[k]; c->cam.v[k] = cam->v[k];
+    }
+    c->cam.lens_radius = cam->lens_radius;
+    c->cam.time_low = cam->time_low;
+    c->cam.time_scale = cam->time_scale;
+    c->has_cam = true;
+    return RRT_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// Pixels of the tiles owned by `rank`, tile by tile (32x8), row-major inside a tile.
+void tile_pixels(uint32_t nx, uint32_t ny, uint32_t rank, uint32_t world, std::vector<uint32_t> &out) {
+    const uint32_t TW = 32, TH = 8;
+    const uint32_t tx_n = (nx + TW - 1) / TW, ty_n = (ny + TH - 1) / TH;
+    out.clear();
+    for (uint32_t t = rank; t < tx_n * ty_n; t += world) {
+        const uint32_t tx = t % tx_n, ty = t / tx_n;
+        for (uint32_t yy = ty * TH; yy < std::min(ny, (ty + 1) * TH); yy++)
+            for (uint32_t xx = tx * TW; xx < std::min(nx, (tx + 1) * TW); xx++) out.push_back(yy * nx + xx);
+    }
+}
+
+int render_impl(rrt_ctx *c, const rrt_render_params *pp, void *d_rgb8, void *d_accum, rrt_stats *stats) {
+    if (!c || !pp) return fail(RRT_ERR_INVALID_ARGUMENT, "null argument");
+    if (!c->has_scene || !c->has_cam) return fail(RRT_ERR_NOT_READY, "render before rrt_upload_scene / rrt_set_camera");
+    const rrt_render_params P = *pp;
+    if (P.nx == 0 || P.ny == 0 || P.ns == 0) return fail(RRT_ERR_INVALID_ARGUMENT, "nx, ny and ns must be positive");
+    if ((uint64_t)P.nx * P.ny > (1ull << 28)) return fail(RRT_ERR_INVALID_ARGUMENT, "image too large");
+    if (P.max_depth > kMaxDepthLimit) return fail(RRT_ERR_INVALID_ARGUMENT, "max_depth too large");
+    const uint32_t world = P.shard_mode == RRT_SHARD_NONE ? 1u : P.shard_world;
+    const uint32_t rank = P.shard_mode == RRT_SHARD_NONE ? 0u : P.shard_rank;
+    if (P.shard_mode > RRT_SHARD_SAMPLE || world == 0 || rank >= world) return fail(RRT_ERR_INVALID_ARGUMENT, "bad shard description");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const uint32_t npix_img = P.nx * P.ny;
+
+    // ---- which pixels and which samples this call renders ----
+    uint32_t npix = npix_img;
+    const uint32_t *d_map = nullptr;
+    if (P.shard_mode == RRT_SHARD_TILE && world > 1) {
+        std::vector<uint32_t> map;
+        tile_pixels(P.nx, P.ny, rank, world, map);
+        npix = (uint32_t)map.size();
+        HIP_TRY(c->pixel_map.ensure(std::max<size_t>(16, map.size() * 4)));
+        if (npix) HIP_TRY(hipMemcpyAsync(c->pixel_map.p, map.data(), map.size() * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));  // `map` dies at the end of this scope
+        d_map = c->pixel_map.as<uint32_t>();
+    }
+    uint32_t k_first = 0, k_step = 1, ns_local = P.ns;
+    if (P.shard_mode == RRT_SHARD_SAMPLE && world > 1) {
+        k_first = rank; k_step = world;
+        ns_local = rank < P.ns ? (P.ns - rank + world - 1) / world : 0;
+    }
+
+    if (d_rgb8) HIP_TRY(hipMemsetAsync(d_rgb8, 0, (size_t)npix_img * 3, s));
+    if (d_accum) HIP_TRY(hipMemsetAsync(d_accum, 0, (size_t)npix_img * 12, s));
+    rrt_stats st{};
+    HIP_TRY(hipEventRecord(c->ev0, s));
+
+    uint32_t n_waves = 0;
+    size_t kev_used = 0;
+    const bool count = P.count_work != 0;
+    const bool time_kernels = count || P.reserved[0] != 0;
+    if (npix > 0 && ns_local > 0) {
+        // ---- batch and slot sizing ----
+        uint32_t batch = P.batch_samples ? P.batch_samples : (uint32_t)std::max<size_t>(1, kRadBudgetBytes / ((size_t)npix * 12));
+        batch = std::min(batch, ns_local);
+        batch = std::min<uint32_t>(batch, std::max<uint32_t>(1, kMaxBatchPaths / npix));
+        const uint32_t rad_plane = batch * npix;
+        uint32_t slots = P.path_slots ? P.path_slots : kDefaultSlots;
+        slots = std::min<uint64_t>(slots, ((uint64_t)rad_plane + kWaveSlots - 1) / kWaveSlots * kWaveSlots);
+        slots = std::max(kWaveSlots, (slots + kWaveSlots - 1) / kWaveSlots * kWaveSlots);
+        n_waves = slots / kWaveSlots;
+        const uint32_t trail_levels = std::max<uint32_t>(1, P.max_depth);
+
+        HIP_TRY(c->rayA.ensure((size_t)slots * 16)); HIP_TRY(c->rayB.ensure((size_t)slots * 16));
+        HIP_TRY(c->rng.ensure((size_t)slots * 16)); HIP_TRY(c->depth.ensure((size_t)slots * 4));
+        HIP_TRY(c->hit.ensure((size_t)slots * 8)); HIP_TRY(c->trail.ensure((size_t)slots * 4 * trail_levels));
+        HIP_TRY(c->queue.ensure((size_t)slots * 4)); HIP_TRY(c->qcount.ensure((size_t)n_waves * 4));
+        HIP_TRY(c->wave_stats.ensure((size_t)n_waves * kWaveStatWords * 8));
+        HIP_TRY(c->cursors.ensure((size_t)kCursorShards * kCursorStride * 4));
+        HIP_TRY(c->flags.ensure(64 * 4)); HIP_TRY(c->stats_out.ensure(kWaveStatWords * 8));
+        HIP_TRY(c->accum.ensure((size_t)npix * 12)); HIP_TRY(c->rad.ensure((size_t)rad_plane * 12));
+
+        PathState ps{};
+        ps.rayA = c->rayA.as<float4>(); ps.rayB = c->rayB.as<float4>(); ps.rng = c->rng.as<uint4>();
+        ps.depth = c->depth.as<uint32_t>(); ps.hit = c->hit.as<uint2>(); ps.trail = c->trail.as<uint32_t>();
+        ps.queue = c->queue.as<uint32_t>(); ps.qcount = c->qcount.as<uint32_t>(); ps.n_slots = slots;
+        uint64_t *wstats = c->wave_stats.as<uint64_t>();
+        HIP_TRY(hipMemsetAsync(wstats, 0, (size_t)n_waves * kWaveStatWords * 8, s));
+        uint32_t *flags = c->flags.as<uint32_t>();
+
+        for (uint32_t s0 = 0; s0 < ns_local; s0 += batch) {
+            const uint32_t nb = std::min(batch, ns_local - s0);
+            BatchDev bd{};
+            bd.nx = P.nx; bd.ny = P.ny; bd.npix = npix; bd.pixel_map = d_map;
+            bd.n_paths = nb * npix;
+            bd.k_first = k_first + s0 * k_step; bd.k_step = k_step;
+            bd.seed = P.seed;
+            bd.rad = c->rad.as<float>(); bd.rad_plane = rad_plane;
+            bd.max_depth = P.max_depth;
+            bd.cursors = c->cursors.as<uint32_t>();
+            bd.n_shards = std::min(kCursorShards, n_waves);
+            bd.alive_flag = flags + kChunk;  // raygen's mark is not looked at
+            HIP_TRY(hipMemsetAsync(bd.cursors, 0, (size_t)kCursorShards * kCursorStride * 4, s));
+            launch_raygen(s, ps, bd, c->cam, wstats);
+            for (;;) {
+                HIP_TRY(hipMemsetAsync(flags, 0, 64 * 4, s));
+                for (uint32_t it = 0; it < kChunk; it++) {
+                    if (time_kernels) {
+                        while (c->kev.size() < kev_used + 2) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); c->kev.push_back(ev); }
+                        HIP_TRY(hipEventRecord(c->kev[kev_used], s));
+                    }
+                    launch_extend(s, c->sd, ps, c->moving, count, wstats);
+                    if (time_kernels) { HIP_TRY(hipEventRecord(c->kev[kev_used + 1], s)); kev_used += 2; }
+                    bd.alive_flag = flags + it;
+                    launch_shade(s, c->sd, ps, bd, c->cam, c->moving, count, wstats);
+                }
+                st.iterations += kChunk;
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipMemcpyAsync(c->h_flags, flags, kChunk * 4, hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                if (c->h_flags[kChunk - 1] == 0) break;
+            }
+            launch_accumulate(s, c->accum.as<float>(), npix, c->rad.as<float>(), rad_plane, nb, s0 == 0);
+        }
+        launch_finalize(s, c->accum.as<float>(), npix, d_map, P.ns, static_cast<uint8_t *>(d_rgb8), static_cast<float *>(d_accum));
+        launch_reduce_stats(s, wstats, n_waves, c->stats_out.as<uint64_t>());
+        HIP_TRY(hipMemcpyAsync(c->h_stats, c->stats_out.p, kWaveStatWords * 8, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipEventRecord(c->ev1, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipGetLastError());
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    st.gpu_ms = ms;
+    if (n_waves) {
+        const uint64_t *h = c->h_stats;
+        st.rays = h[ST_RAYS]; st.inner_visits = h[ST_INNER]; st.leaf_tests = h[ST_LEAF];
+        st.hits_lambertian = h[ST_HL]; st.hits_metal = h[ST_HM]; st.hits_dielectric = h[ST_HD];
+        st.sky_misses = h[ST_SKY]; st.paths = h[ST_PATHS]; st.depth_cut = h[ST_DEPTHCUT]; st.absorbed = h[ST_ABSORBED];
+    }
+    double ext = 0.0;
+    for (size_t i = 0; i + 1 < kev_used; i += 2) {
+        float m = 0.f;
+        if (hipEventElapsedTime(&m, c->kev[i], c->kev[i + 1]) == hipSuccess) ext += m;
+    }
+    st.extend_ms = ext;
+    st.extend_launches = kev_used / 2;
+    if (stats) *stats = st;
+    return RRT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rrt_render_device(rrt_ctx *c, const rrt_render_params *p, void *d_rgb8, void *d_accum, rrt_stats *stats) {
+    return render_impl(c, p, d_rgb8, d_accum, stats);
+}
+
+int rrt_render(rrt_ctx *c, const rrt_render_params *p, uint8_t *out_rgb8, float *out_accum, rrt_stats *stats, volatile uint64_t *progress) {
+    if (!c || !p) return fail(RRT_ERR_INVALID_ARGUMENT, "null argument");
+    if (!out_rgb8) return fail(RRT_ERR_INVALID_ARGUMENT, "out_rgb8 is null");
+    const size_t npix = (size_t)p->nx * p->ny;
+    if (npix == 0) return fail(RRT_ERR_INVALID_ARGUMENT, "nx and ny must be positive");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(c->tmp_rgb.ensure(npix * 3));
+    if (out_accum) HIP_TRY(c->tmp_acc.ensure(npix * 12));
+    int rc = render_impl(c, p, c->tmp_rgb.p, out_accum ? c->tmp_acc.p : nullptr, stats);
+    if (rc != RRT_OK) return rc;
+    HIP_TRY(hipMemcpy(out_rgb8, c->tmp_rgb.p, npix * 3, hipMemcpyDeviceToHost));
+    if (out_accum) HIP_TRY(hipMemcpy(out_accum, c->tmp_acc.p, npix * 12, hipMemcpyDeviceToHost));
+    if (progress) *progress = npix;  // every pixel is finished when the call returns (lib.rs:109)
+    return RRT_OK;
+}
+
+int rrt_validate_scene(const rrt_sphere_soa *sp, const rrt_material_soa *mt, const rrt_bvh_node *nodes, uint32_t n_nodes) {
+    SceneLayout L;
+    std::string err;
+    int rc = build_scene_layout(sp, mt, nodes, n_nodes, L, err);
+    if (rc != RRT_OK) return fail(rc, err);
+    return RRT_OK;
+}
+
+int rrt_debug_layout(const rrt_sphere_soa *sp, const rrt_material_soa *mt, const rrt_bvh_node *nodes, uint32_t n_nodes, uint32_t *words16,
+                     uint32_t *root_ref, uint32_t *scene_flags) {
+    SceneLayout L;
+    std::string err;
+    int rc = build_scene_layout(sp, mt, nodes, n_nodes, L, err);
+    if (rc != RRT_OK) return fail(rc, err);
+    if (words16) std::memcpy(words16, L.nodes.data(), L.nodes.size() * 4);
+    if (root_ref) *root_ref = L.root_ref;
+    if (scene_flags) *scene_flags = L.flags;
+    return RRT_OK;
+}
+
+uint32_t rrt_shard_pixels(uint32_t nx, uint32_t ny, uint32_t shard_mode, uint32_t rank, uint32_t world, uint32_t *out_idx) {
+    if (shard_mode == RRT_SHARD_TILE && world > 1) {
+        if (rank >= world) return 0;
+        std::vector<uint32_t> map;
+        tile_pixels(nx, ny, rank, world, map);
+        if (out_idx) std::memcpy(out_idx, map.data(), map.size() * 4);
+        return (uint32_t)map.size();
+    }
+    const uint32_t n = nx * ny;
+    if (out_idx) for (uint32_t i = 0; i < n; i++) out_idx[i] = i;
+    return n;
+}
+
+int rrt_finalize(rrt_ctx *c, const void *d_accum, uint32_t n_pixels, uint32_t ns, void *d_rgb8) {
+    if (!c || !d_accum || !d_rgb8 || ns == 0) return fail(RRT_ERR_INVALID_ARGUMENT, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    if (n_pixels) launch_finalize_interleaved(c->stream, static_cast<const float *>(d_accum), n_pixels, ns, static_cast<uint8_t *>(d_rgb8));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RRT_OK;
+}
+
+int rrt_intersect(rrt_ctx *c, uint32_t n, const float *org, const float *dir, const float *time, float t_min, float t_max, float *out_t,
+                  uint32_t *out_obj) {
+    if (!c || !org || !dir || !out_t || !out_obj) return fail(RRT_ERR_INVALID_ARGUMENT, "null argument");
+    if (!c->has_scene) return fail(RRT_ERR_NOT_READY, "rrt_intersect before rrt_upload_scene");
+    if (n == 0) return RRT_OK;
+    if (n > (1u << 28)) return fail(RRT_ERR_INVALID_ARGUMENT, "too many rays");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    HIP_TRY(c->q_org.ensure((size_t)n * 12)); HIP_TRY(c->q_dir.ensure((size_t)n * 12)); HIP_TRY(c->q_time.ensure((size_t)n * 4));
+    HIP_TRY(c->q_t.ensure((size_t)n * 4)); HIP_TRY(c->q_obj.ensure((size_t)n * 4));
+    HIP_TRY(hipMemcpyAsync(c->q_org.p, org, (size_t)n * 12, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->q_dir.p, dir, (size_t)n * 12, hipMemcpyHostToDevice, s));
+    if (time) HIP_TRY(hipMemcpyAsync(c->q_time.p, time, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    launch_intersect(s, c->sd, c->moving, n, c->q_org.as<float>(), c->q_dir.as<float>(), time ? c->q_time.as<float>() : nullptr, t_min,
+                     t_max, c->q_t.as<float>(), c->q_obj.as<uint32_t>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_t, c->q_t.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(out_obj, c->q_obj.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return RRT_OK;
+}
+
+}  // extern "C"

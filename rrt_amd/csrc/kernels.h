@@ -1,0 +1,82 @@
+// Device-side data layout and launch entry points of the wavefront path tracer.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace rrt_amd {
+
+constexpr uint32_t kWaveSlots = 256;     // path slots owned by one wave (4 tiles of 64 lanes)
+constexpr uint32_t kBlockThreads = 256;  // 4 waves per workgroup
+constexpr uint32_t kCursorShards = 64;   // sharded path cursors, one 128-byte line each
+constexpr uint32_t kCursorStride = 32;   // uint32 words between two cursors
+constexpr uint32_t kWaveStatWords = 16;  // uint64 counters per wave
+constexpr uint32_t kPrimNone = 0xFFFFFFFFu;
+
+// Indices into a wave's counter row
+enum { ST_RAYS = 0, ST_INNER, ST_LEAF, ST_HL, ST_HM, ST_HD, ST_SKY, ST_PATHS, ST_DEPTHCUT, ST_ABSORBED };
+
+struct CameraDev {  // camera.rs:5-16
+    float llc[3], hor[3], ver[3], org[3], u[3], v[3];
+    float lens_radius, time_low, time_scale;
+};
+
+struct SceneDev {
+    const uint4 *nodes;  // 4 x uint4 per node (see scene_layout.h)
+    uint32_t root_ref;
+    const float4 *sph;        // {centre0, radius}
+    const float4 *motion;     // {centre1 - centre0, time0}
+    const float *motion_dt;   // time1 - time0
+    const uint32_t *sph_info;
+    const float4 *mat;        // {albedo, fuzz | ref_idx}
+    const float4 *prim_att;   // attenuation per sphere
+    uint32_t flags;
+    float u_time0, u_dt;
+};
+
+// All per-path state lives in planes indexed by slot.  A wave owns slots [wave*kWaveSlots, +kWaveSlots)
+// and the matching stretch of `queue`, which lists its live slots; `qcount[wave]` is the list length.
+struct PathState {
+    float4 *rayA;      // origin xyz, time
+    float4 *rayB;      // direction xyz, path id within the batch (as bits)
+    uint4 *rng;        // Xoshiro128Plus state
+    uint32_t *depth;   // scatters so far
+    uint2 *hit;        // extend -> shade: {t bits, sphere index or kPrimNone}
+    uint32_t *trail;   // [depth][slot] sphere hit at each scatter, for the back-to-front product
+    uint32_t *queue;
+    uint32_t *qcount;
+    uint32_t n_slots;  // multiple of kWaveSlots
+};
+
+struct BatchDev {
+    uint32_t nx, ny;
+    uint32_t npix;             // pixels this call renders
+    const uint32_t *pixel_map; // local pixel -> image pixel index (lib.rs:93-94 idx); null = identity
+    uint32_t n_paths;          // npix * samples in this batch
+    uint32_t k_first, k_step;  // sample index of local sample j is k_first + j * k_step
+    uint64_t seed;
+    float *rad;                // 3 planes of rad_plane floats: radiance of each path of the batch
+    uint32_t rad_plane;
+    uint32_t max_depth;
+    uint32_t *cursors;         // n_shards counters, kCursorStride words apart
+    uint32_t n_shards;         // min(kCursorShards, waves): every shard must be served by at least one wave
+    uint32_t *alive_flag;      // set to 1 by any wave that still owns live paths after shading
+};
+
+void launch_raygen(hipStream_t s, const PathState &P, const BatchDev &B, const CameraDev &C, uint64_t *wave_stats);
+void launch_extend(hipStream_t s, const SceneDev &S, const PathState &P, bool moving, bool count, uint64_t *wave_stats);
+void launch_shade(hipStream_t s, const SceneDev &S, const PathState &P, const BatchDev &B, const CameraDev &C, bool moving,
+                  bool count, uint64_t *wave_stats);
+// accum[3][npix] += rad planes, sample by sample in order (lib.rs:96-103)
+void launch_accumulate(hipStream_t s, float *accum, uint32_t npix, const float *rad, uint32_t rad_plane, uint32_t n_samples,
+                       bool first_batch);
+// lib.rs:105-108 for local pixel planes -> interleaved RGB8 / float sums at image positions
+void launch_finalize(hipStream_t s, const float *accum, uint32_t npix, const uint32_t *pixel_map, uint32_t ns, uint8_t *rgb8,
+                     float *accum_out);
+// rgb8 from interleaved float sums (lib.rs:105-108)
+void launch_finalize_interleaved(hipStream_t s, const float *accum_rgb, uint32_t n_pixels, uint32_t ns, uint8_t *rgb8);
+void launch_intersect(hipStream_t s, const SceneDev &S, bool moving, uint32_t n, const float *org, const float *dir,
+                      const float *time, float t_min, float t_max, float *out_t, uint32_t *out_obj);
+void launch_reduce_stats(hipStream_t s, const uint64_t *wave_stats, uint32_t n_waves, uint64_t *out16);
+
+}  // namespace rrt_amd

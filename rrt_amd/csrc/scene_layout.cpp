@@ -1,0 +1,144 @@
+#include "scene_layout.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace rrt_amd {
+namespace {
+
+inline uint32_t f2u(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+inline bool is_neg_zero(float f) { return f2u(f) == 0x80000000u; }
+inline bool is_leaf(const rrt_bvh_node &n) { return (n.right_axis_leaf & RRT_NODE_LEAF_BIT) != 0; }
+
+}  // namespace
+
+int build_scene_layout(const rrt_sphere_soa *sp, const rrt_material_soa *mt, const rrt_bvh_node *nodes, uint32_t n_nodes,
+                       SceneLayout &out, std::string &err) {
+    if (!sp || !mt || !nodes) { err = "null scene argument"; return RRT_ERR_INVALID_ARGUMENT; }
+    if (sp->n == 0 || n_nodes == 0) {
+        // Bvh::hit indexes nodes[0] unconditionally (acceleration.rs:233,237): an empty scene panics there.
+        err = "empty scene: the reference cannot render it either (Bvh::hit indexes nodes[0])";
+        return RRT_ERR_BAD_SCENE;
+    }
+    if (n_nodes > kRefIndexMask) { err = "too many BVH nodes"; return RRT_ERR_BAD_SCENE; }
+    if (sp->n > kInfoMatMask || mt->n > kInfoMatMask) { err = "too many spheres or materials"; return RRT_ERR_BAD_SCENE; }
+    if (!sp->c0x || !sp->c0y || !sp->c0z || !sp->c1x || !sp->c1y || !sp->c1z || !sp->time0 || !sp->time1 || !sp->radius ||
+        !sp->material_id) { err = "null sphere plane"; return RRT_ERR_INVALID_ARGUMENT; }
+    if (mt->n == 0 || !mt->kind || !mt->albedo_r || !mt->albedo_g || !mt->albedo_b || !mt->fuzz || !mt->ref_idx) {
+        err = "null material plane"; return RRT_ERR_INVALID_ARGUMENT;
+    }
+
+    const uint32_t ns = sp->n;
+    out = SceneLayout();
+    out.n_spheres = ns;
+    out.n_nodes = n_nodes;
+
+    // ---- materials ----
+    out.mat.resize(mt->n);
+    for (uint32_t m = 0; m < mt->n; m++) {
+        if (mt->kind[m] > RRT_MAT_DIELECTRIC) { err = "unknown material kind"; return RRT_ERR_BAD_SCENE; }
+        const float param = mt->kind[m] == RRT_MAT_METAL ? mt->fuzz[m] : (mt->kind[m] == RRT_MAT_DIELECTRIC ? mt->ref_idx[m] : 0.f);
+        out.mat[m] = Float4{mt->albedo_r[m], mt->albedo_g[m], mt->albedo_b[m], param};
+    }
+
+    // ---- spheres ----
+    out.sph.resize(ns); out.motion.resize(ns); out.motion_dt.resize(ns); out.sph_info.resize(ns); out.prim_att.resize(ns);
+    bool any_moving = false, uniform = true;
+    uint32_t ut0 = 0, ut1 = 0;
+    for (uint32_t i = 0; i < ns; i++) {
+        const uint32_t m = sp->material_id[i];
+        if (m >= mt->n) { err = "sphere material_id out of range"; return RRT_ERR_BAD_SCENE; }
+        const float c0[3] = {sp->c0x[i], sp->c0y[i], sp->c0z[i]};
+        const float c1[3] = {sp->c1x[i], sp->c1y[i], sp->c1z[i]};
+        // Sphere::center_at (sphere.rs:61-64) returns centre0 bit for bit when centre1 == centre0, the times
+        // are the (0, 1) of Sphere::from (sphere.rs:57-59) and no component is -0.0 (which "+ 0" would turn
+        // into +0.0).  Only those spheres skip the interpolation; every other sphere evaluates it in full.
+        bool still = f2u(sp->time0[i]) == 0u && sp->time1[i] == 1.0f;
+        for (int k = 0; k < 3; k++) still = still && f2u(c0[k]) == f2u(c1[k]) && !is_neg_zero(c0[k]);
+        out.sph[i] = Float4{c0[0], c0[1], c0[2], sp->radius[i]};
+        out.motion[i] = Float4{c1[0] - c0[0], c1[1] - c0[1], c1[2] - c0[2], sp->time0[i]};
+        out.motion_dt[i] = sp->time1[i] - sp->time0[i];
+        out.sph_info[i] = m | (mt->kind[m] << kInfoKindShift) | (still ? 0u : kInfoMovingBit);
+        if (mt->kind[m] == RRT_MAT_DIELECTRIC) out.prim_att[i] = Float4{1.f, 1.f, 1.f, 0.f};
+        else out.prim_att[i] = Float4{mt->albedo_r[m], mt->albedo_g[m], mt->albedo_b[m], 1.f};
+        if (!still) {
+            if (!any_moving) { ut0 = f2u(sp->time0[i]); ut1 = f2u(sp->time1[i]); out.u_time0 = sp->time0[i]; out.u_dt = out.motion_dt[i]; }
+            else if (ut0 != f2u(sp->time0[i]) || ut1 != f2u(sp->time1[i])) uniform = false;
+            any_moving = true;
+        }
+    }
+    if (any_moving) out.flags |= kSceneHasMoving;
+    if (any_moving && uniform) out.flags |= kSceneUniformTimes;
+
+    // ---- tree validation: every node reachable from the root exactly once, indices in range ----
+    std::vector<uint8_t> seen(n_nodes, 0);
+    struct Item { uint32_t node; uint32_t depth; };
+    std::vector<Item> stack;
+    stack.push_back({0u, 0u});
+    uint32_t visited = 0;
+    while (!stack.empty()) {
+        Item it = stack.back(); stack.pop_back();
+        if (it.node >= n_nodes) { err = "BVH child index out of range"; return RRT_ERR_BAD_SCENE; }
+        if (seen[it.node]) { err = "BVH is not a tree (node reached twice)"; return RRT_ERR_BAD_SCENE; }
+        seen[it.node] = 1; visited++;
+        const rrt_bvh_node &n = nodes[it.node];
+        if (is_leaf(n)) {
+            if (n.left_or_obj >= ns) { err = "BVH leaf object index out of range"; return RRT_ERR_BAD_SCENE; }
+            if (it.depth > out.max_leaf_depth) out.max_leaf_depth = it.depth;
+        } else {
+            const uint32_t axis = (n.right_axis_leaf >> RRT_NODE_AXIS_SHIFT) & 3u;
+            if (axis > 2) { err = "BVH inner node axis out of range"; return RRT_ERR_BAD_SCENE; }
+            stack.push_back({n.right_axis_leaf & RRT_NODE_INDEX_MASK, it.depth + 1});
+            stack.push_back({n.left_or_obj, it.depth + 1});
+        }
+    }
+    (void)visited;  // unreachable nodes are never visited by Bvh::hit either
+
+    auto ref_of = [&](uint32_t idx) { return idx | (is_leaf(nodes[idx]) ? kRefLeafBit : 0u); };
+
+    // ---- node words ----
+    out.nodes.assign(static_cast<size_t>(n_nodes) * kNodeWords, 0u);
+    for (uint32_t i = 0; i < n_nodes; i++) {
+        if (!seen[i]) continue;
+        uint32_t *w = &out.nodes[static_cast<size_t>(i) * kNodeWords];
+        const rrt_bvh_node &n = nodes[i];
+        if (is_leaf(n)) {
+            const uint32_t p = n.left_or_obj;
+            const float r = out.sph[p].w;
+            w[0] = f2u(out.sph[p].x); w[1] = f2u(out.sph[p].y); w[2] = f2u(out.sph[p].z);
+            w[3] = f2u(r * r);  // self.radius * self.radius (sphere.rs:73)
+            w[4] = p;
+            w[5] = (out.sph_info[p] & kInfoMovingBit) ? 1u : 0u;
+        } else {
+            for (int k = 0; k < 3; k++) { w[k] = f2u(n.min[k]); w[3 + k] = f2u(n.max[k]); }
+            const uint32_t axis = (n.right_axis_leaf >> RRT_NODE_AXIS_SHIFT) & 3u;
+            w[6] = ref_of(n.right_axis_leaf & RRT_NODE_INDEX_MASK) | (axis << RRT_NODE_AXIS_SHIFT);
+            w[7] = ref_of(n.left_or_obj);
+        }
+    }
+    out.root_ref = ref_of(0);
+
+    // ---- exit links: for octant o, the order of acceleration.rs:253-267 is fixed, so the node popped after a
+    //      subtree is known ahead of time.  near = right when the ray is negative along the node's axis. ----
+    struct Link { uint32_t node, exit_ref; };
+    std::vector<Link> ls;
+    for (uint32_t oct = 0; oct < 8; oct++) {
+        ls.clear();
+        ls.push_back({0u, kRefEnd});
+        while (!ls.empty()) {
+            Link l = ls.back(); ls.pop_back();
+            out.nodes[static_cast<size_t>(l.node) * kNodeWords + 8 + oct] = l.exit_ref;
+            const rrt_bvh_node &n = nodes[l.node];
+            if (is_leaf(n)) continue;
+            const uint32_t axis = (n.right_axis_leaf >> RRT_NODE_AXIS_SHIFT) & 3u;
+            const uint32_t left = n.left_or_obj, right = n.right_axis_leaf & RRT_NODE_INDEX_MASK;
+            const bool neg = (oct >> axis) & 1u;
+            const uint32_t near_i = neg ? right : left, far_i = neg ? left : right;
+            ls.push_back({far_i, l.exit_ref});
+            ls.push_back({near_i, ref_of(far_i)});
+        }
+    }
+    return RRT_OK;
+}
+
+}  // namespace rrt_amd

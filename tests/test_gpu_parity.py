@@ -1,0 +1,262 @@
+"""GPU path vs CPU oracle, through the C ABI.  Bit-exact: f32 sums compared as bit patterns, RGB8 equal,
+work counters equal.  Everything here needs an MI355X."""
+import numpy as np
+import pytest
+
+import rrt_amd
+from oracle import MODE_PER_SAMPLE, OracleScene
+from tests.conftest import scene_arrays_from_oracle
+
+pytestmark = pytest.mark.gpu
+
+SCENES = {"chap11": rrt_amd.SCENE_CHAP11, "chap12": rrt_amd.SCENE_CHAP12, "book2chap2": rrt_amd.SCENE_BOOK2CHAP2}
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def upload_from_oracle(ctx, osc):
+    sp, mid, mt, nd, cam21 = scene_arrays_from_oracle(osc)
+    ctx.upload_scene(sp, mid, mt, nd)
+    cam = rrt_amd.Camera.from_buffer_copy(cam21.tobytes())
+    ctx.set_camera(cam)
+
+
+def assert_same_image(gpu, ref):
+    rgb_g, acc_g, st_g = gpu
+    rgb_o, acc_o, ct_o = ref
+    nbad = int((bits(acc_g) != bits(acc_o)).sum())
+    assert nbad == 0, f"{nbad} of {acc_o.size} f32 sums differ; max abs err {np.abs(acc_g - acc_o).max()}"
+    assert np.array_equal(rgb_g, rgb_o)
+    assert st_g["rays"] == ct_o["rays"]
+    assert st_g["paths"] == ct_o["paths"]
+
+
+# ---------------------------------------------------------------- extend alone: Bvh::hit
+@pytest.mark.parametrize("name", list(SCENES))
+def test_intersect_primary_rays(gpu_ctx, name):
+    nx, ny = 96, 64
+    osc = OracleScene.build(SCENES[name], nx, ny, seed=0)
+    upload_from_oracle(gpu_ctx, osc)
+    idx = np.tile(np.arange(nx * ny, dtype=np.uint32), 2)
+    k = np.repeat(np.arange(2, dtype=np.uint32), nx * ny)
+    rays, _ = osc.gen_primary(nx, ny, 7, idx, k)
+    t_o, obj_o, _, _, _ = osc.hit_rays(rays[:, 0:3], rays[:, 3:6], rays[:, 6])
+    t_g, obj_g = gpu_ctx.intersect(rays[:, 0:3], rays[:, 3:6], rays[:, 6])
+    assert np.array_equal(obj_g, obj_o)
+    assert np.array_equal(bits(t_g), bits(t_o))
+    assert (obj_o != 0xFFFFFFFF).sum() > 100  # the test is not vacuous
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_intersect_random_and_degenerate_rays(gpu_ctx, name):
+    osc = OracleScene.build(SCENES[name], 64, 64, seed=3)
+    upload_from_oracle(gpu_ctx, osc)
+    rng = np.random.default_rng(5)
+    n = 20000
+    org = rng.uniform(-12, 12, (n, 3)).astype(np.float32)
+    org[:, 1] = rng.uniform(0.05, 3.0, n)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    # axis-parallel and zero components: 1/0 = inf, 0*inf = NaN in the slab test (acceleration.rs:81-82)
+    d[0:2000, 0] = 0.0
+    d[2000:4000, 1] = 0.0
+    d[4000:6000, 2] = -0.0
+    d[6000:6500, 0:2] = 0.0
+    tm = rng.uniform(0, 1, n).astype(np.float32)
+    t_o, obj_o, _, _, _ = osc.hit_rays(org, d, tm)
+    t_g, obj_g = gpu_ctx.intersect(org, d, tm)
+    assert np.array_equal(obj_g, obj_o)
+    assert np.array_equal(bits(t_g), bits(t_o))
+    # brute force (lib.rs:32-47) agrees wherever the closest t is unique
+    t_b, obj_b, _, _, _ = osc.hit_rays(org, d, tm, brute=True)
+    assert np.array_equal(bits(t_b), bits(t_o))
+
+
+# ---------------------------------------------------------------- whole path: tracescene
+@pytest.mark.parametrize("name,nx,ny,ns", [
+    ("chap11", 40, 23, 8),       # the chap11 fixture shape
+    ("chap12", 10, 10, 4),       # benches/benchmark.rs:11-13
+    ("chap12", 96, 64, 16),
+    ("book2chap2", 96, 64, 8),
+    ("chap12", 1, 1, 3),
+    ("chap11", 7, 1, 1),
+])
+def test_render_bit_exact(gpu_ctx, name, nx, ny, ns):
+    osc = OracleScene.build(SCENES[name], nx, ny, seed=0)
+    upload_from_oracle(gpu_ctx, osc)
+    ref = osc.render(nx, ny, ns, seed=11, mode=MODE_PER_SAMPLE, threads=8)
+    gpu = gpu_ctx.render(rrt_amd.Context.params(nx, ny, ns, seed=11))
+    assert_same_image(gpu, ref)
+    assert gpu[2]["progress"] == nx * ny
+
+
+@pytest.mark.parametrize("name", ["chap11", "chap12", "book2chap2"])
+def test_work_counters_match(gpu_ctx, name):
+    nx, ny, ns = 64, 48, 6
+    osc = OracleScene.build(SCENES[name], nx, ny, seed=0)
+    upload_from_oracle(gpu_ctx, osc)
+    _, _, ct = osc.render(nx, ny, ns, seed=5, threads=8)
+    gpu = gpu_ctx.render(rrt_amd.Context.params(nx, ny, ns, seed=5, count_work=True))
+    st = gpu[2]
+    for key in ("rays", "inner_visits", "leaf_tests", "hits_lambertian", "hits_metal", "hits_dielectric", "sky_misses", "paths",
+                "depth_cut", "absorbed"):
+        assert st[key] == ct[key], key
+    # the counting build computes the same image
+    plain = gpu_ctx.render(rrt_amd.Context.params(nx, ny, ns, seed=5))
+    assert np.array_equal(bits(plain[1]), bits(gpu[1]))
+
+
+@pytest.mark.parametrize("max_depth", [0, 1, 2, 50])
+def test_depth_limit(gpu_ctx, max_depth):
+    nx, ny, ns = 48, 32, 4
+    osc = OracleScene.build(SCENES["chap11"], nx, ny, seed=0)
+    upload_from_oracle(gpu_ctx, osc)
+    ref = osc.render(nx, ny, ns, seed=2, max_depth=max_depth, threads=4)
+    gpu = gpu_ctx.render(rrt_amd.Context.params(nx, ny, ns, seed=2, max_depth=max_depth))
+    assert_same_image(gpu, ref)
+
+
+def test_schedule_independence(gpu_ctx):
+    """Slots in flight and batch size change the schedule, never a bit of the result."""
+    nx, ny, ns = 80, 50, 12
+    osc = OracleScene.build(SCENES["book2chap2"], nx, ny, seed=1)
+    upload_from_oracle(gpu_ctx, osc)
+    ref = osc.render(nx, ny, ns, seed=9, threads=8)
+    for slots, batch in [(256, 1), (1024, 5), (4096, 12), (0, 0), (256 * 70, 7)]:
+        gpu = gpu_ctx.render(rrt_amd.Context.params(nx, ny, ns, seed=9, path_slots=slots, batch_samples=batch))
+        assert_same_image(gpu, ref)
+
+
+def test_tile_sharding_composes_to_the_unsharded_image(gpu_ctx):
+    nx, ny, ns = 100, 37, 6   # not a multiple of the 32x8 tile in either direction
+    osc = OracleScene.build(SCENES["chap12"], nx, ny, seed=0)
+    upload_from_oracle(gpu_ctx, osc)
+    full = gpu_ctx.render(rrt_amd.Context.params(nx, ny, ns, seed=4))
+    for world in (2, 3, 8):
+        rgb = np.zeros_like(full[0])
+        acc = np.zeros_like(full[1])
+        owned = np.zeros(nx * ny, np.int32)
+        rays = 0
+        for rank in range(world):
+            r, a, st = gpu_ctx.render(rrt_amd.Context.params(nx, ny, ns, seed=4, shard_mode=rrt_amd.SHARD_TILE, rank=rank, world=world))
+            px = rrt_amd.shard_pixels(nx, ny, rrt_amd.SHARD_TILE, rank, world)
+            owned[px] += 1
+            mask = np.zeros(nx * ny, bool)
+            mask[px] = True
+            mask = mask.reshape(ny, nx)
+            assert not r[~mask].any() and not a[~mask].any()   # nothing written outside the shard
+            rgb += r
+            acc += a
+            rays += st["rays"]
+        assert (owned == 1).all()
+        assert np.array_equal(rgb, full[0])
+        assert np.array_equal(bits(acc), bits(full[1]))
+        assert rays == full[2]["rays"]
+
+
+def test_sample_sharding_matches_oracle_strides(gpu_ctx):
+    nx, ny, ns, world = 60, 40, 10, 3
+    osc = OracleScene.build(SCENES["chap12"], nx, ny, seed=0)
+    upload_from_oracle(gpu_ctx, osc)
+    total = np.zeros((ny, nx, 3), np.float64)
+    for rank in range(world):
+        _, a, st = gpu_ctx.render(rrt_amd.Context.params(nx, ny, ns, seed=4, shard_mode=rrt_amd.SHARD_SAMPLE, rank=rank, world=world))
+        _, a_o, ct = osc.render(nx, ny, ns, seed=4, k_begin=rank, k_step=world, threads=8)
+        assert np.array_equal(bits(a), bits(a_o))
+        assert st["rays"] == ct["rays"]
+        total += a
+    _, full, _ = osc.render(nx, ny, ns, seed=4, threads=8)
+    # a different order of f32 additions: equal up to rounding of ns additions
+    assert np.allclose(total, full, rtol=2e-6, atol=1e-6)
+
+
+def test_custom_scene_general_motion(gpu_ctx):
+    """Spheres whose shutter intervals differ (per-sphere division), a -0.0 centre component, a negative radius,
+    a one-sphere scene (root is a leaf)."""
+    rng = np.random.default_rng(1)
+    n = 40
+    sp = np.zeros((n, 9), np.float32)
+    sp[:, 0:3] = rng.uniform(-3, 3, (n, 3))
+    sp[:, 3:6] = sp[:, 0:3] + rng.uniform(-0.4, 0.4, (n, 3)) * (rng.uniform(size=(n, 1)) < 0.5)
+    sp[:, 6] = rng.choice([0.0, 0.25], n)
+    sp[:, 7] = rng.choice([1.0, 0.75, 2.0], n)
+    sp[:, 8] = rng.uniform(0.2, 0.6, n)
+    sp[0, 0] = -0.0
+    sp[0, 3] = -0.0
+    sp[1, 8] = -0.3
+    mt = np.zeros((n, 6), np.float32)
+    mt[:, 0] = rng.integers(0, 3, n)
+    mt[:, 1:4] = rng.uniform(0.1, 0.9, (n, 3))
+    mt[:, 4] = rng.uniform(0, 0.5, n)
+    mt[:, 5] = 1.5
+    mid = np.arange(n, dtype=np.uint32)
+    cam = rrt_amd.camera_from((0, 1, 9), (0, 0, 0), (0, 1, 0), 40.0, 1.5, 0.05, 9.0, 0.0, 1.0)
+    for count in (n, 1):
+        osc = OracleScene.from_arrays(sp[:count], mid[:count], mt[:count], np.zeros((0, 8), np.uint32), cam.as_array())
+        osc.build_bvh(0)
+        _, _, _, nd, _ = scene_arrays_from_oracle(osc)
+        gpu_ctx.upload_scene(sp[:count], mid[:count], mt[:count], nd)
+        gpu_ctx.set_camera(cam)
+        nx, ny, ns = 60, 40, 6
+        ref = osc.render(nx, ny, ns, seed=3, threads=8)
+        gpu = gpu_ctx.render(rrt_amd.Context.params(nx, ny, ns, seed=3))
+        assert_same_image(gpu, ref)
+
+
+def test_tracescene_mirror(gpu_ctx):
+    """The reference's call sequence end to end: chap12_scene -> init_pool_with_rng -> tracescene (benches/benchmark.rs:14-23)."""
+    nx, ny, ns = 10, 10, 4
+    hs = rrt_amd.HostScene(rrt_amd.SCENE_CHAP12, nx, ny, seed=0)
+    px, pdc, stream_seed = hs.tracescene(ns, device=0)
+    assert pdc == nx * ny
+    osc = OracleScene.build(rrt_amd.SCENE_CHAP12, nx, ny, seed=0)
+    rgb_o, _, _ = osc.render(nx, ny, ns, seed=stream_seed)
+    assert np.array_equal(px, rgb_o)
+
+
+def test_errors(gpu_ctx):
+    fresh = rrt_amd.Context(0)
+    with pytest.raises(rrt_amd.RrtError, match="before"):
+        fresh.render(rrt_amd.Context.params(4, 4, 1))
+    fresh.close()
+    osc = OracleScene.build(SCENES["chap11"], 8, 8)
+    upload_from_oracle(gpu_ctx, osc)
+    with pytest.raises(rrt_amd.RrtError):
+        gpu_ctx.render(rrt_amd.Context.params(0, 4, 1))
+    with pytest.raises(rrt_amd.RrtError):
+        gpu_ctx.render(rrt_amd.Context.params(4, 4, 1, shard_mode=rrt_amd.SHARD_TILE, rank=2, world=2))
+
+
+# ---------------------------------------------------------------- full-size configurations
+def spot_check(gpu_ctx, kind, nx, ny, ns, seed, n_pixels, scene_seed=0, half=11):
+    osc = OracleScene.build(kind, nx, ny, seed=scene_seed, half=half)
+    upload_from_oracle(gpu_ctx, osc)
+    rgb, acc, st = gpu_ctx.render(rrt_amd.Context.params(nx, ny, ns, seed=seed))
+    idx = np.random.default_rng(0).choice(nx * ny, n_pixels, replace=False).astype(np.uint32)
+    acc_o, rgb_o, _ = osc.render_pixels(nx, ny, ns, seed, idx)
+    assert np.array_equal(bits(acc.reshape(-1, 3)[idx]), bits(acc_o))
+    assert np.array_equal(rgb.reshape(-1, 3)[idx], rgb_o)
+    assert st["paths"] == nx * ny * ns
+    assert rgb.mean() > 20  # an image, not zeros
+    return rgb, acc, st
+
+
+def test_full_chap11_400x225x100(gpu_ctx):
+    nx, ny, ns = 400, 225, 100
+    osc = OracleScene.build(SCENES["chap11"], nx, ny)
+    upload_from_oracle(gpu_ctx, osc)
+    ref = osc.render(nx, ny, ns, seed=0, threads=16)
+    gpu = gpu_ctx.render(rrt_amd.Context.params(nx, ny, ns, seed=0))
+    assert_same_image(gpu, ref)
+
+
+def test_full_chap12_1200x800x500_spot(gpu_ctx):
+    rgb, acc, st = spot_check(gpu_ctx, SCENES["chap12"], 1200, 800, 500, seed=0, n_pixels=96)
+    # a second schedule of the same render gives the same image
+    rgb2, acc2, st2 = gpu_ctx.render(rrt_amd.Context.params(1200, 800, 500, seed=0, path_slots=1 << 19, batch_samples=50))
+    assert np.array_equal(rgb, rgb2) and np.array_equal(bits(acc), bits(acc2)) and st["rays"] == st2["rays"]
+
+
+def test_full_book2chap2_1200x800_spot(gpu_ctx):
+    spot_check(gpu_ctx, SCENES["book2chap2"], 1200, 800, 100, seed=0, n_pixels=64)
