@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s of the GPU render path on the chap12 random-spheres scene.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One step = one full render of the workload: chap12 scene (seed 0, 484 spheres / 967 BVH nodes),
+1200x800 pixels, 500 samples per pixel, depth 50 — every primary ray, BVH walk, sphere test, scatter
+and the framebuffer accumulation/quantisation.  Rays = calls of Bvh::hit (lib.rs:57), counted on the
+device.  The scene is uploaded before the timed region; the image stays in HBM.
+
+N > 1 (one process per GPU, torch.distributed over RCCL): weak scaling by sample sharding — the job
+is the same image at 500*N samples per pixel, rank r renders samples k = r (mod N) and the f32
+framebuffers are summed onto rank 0 with one reduce over xGMI, then quantised there.
+
+Rank 0 prints one JSON line.  `roofline` prices the extend kernel (BVH walk + sphere quadratic)
+against the FP32 vector peak; `cpu_baseline` is the C restatement of the reference's threaded CPU
+renderer (oracle/) on a bounded sample of the same workload, on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NX, NY, NS, MAX_DEPTH, SEED = 1200, 800, 500, 50, 0
+FP32_VECTOR_PEAK_TFLOPS = 157.3   # 256 CU x 4 SIMD x 32 lanes x 2 (packed) x 2 (fma) x 2.4 GHz
+HBM_PEAK_GBS = 8000.0
+
+
+def extend_flops(st):
+    """Algorithmic FLOPs of the extend kernel: 3 divisions for 1/direction per ray, 22 per slab test, 39 per sphere test."""
+    return 3 * st["rays"] + 22 * st["inner_visits"] + 39 * st["leaf_tests"]
+
+
+def extend_bytes(st):
+    """Algorithmic bytes of the extend kernel: 32 B box+topology per inner visit, 36 B per sphere test,
+    ray in (32 B + 4 B list entry) and hit out (8 B) per ray."""
+    return 32 * st["inner_visits"] + 36 * st["leaf_tests"] + 44 * st["rays"]
+
+
+def cpu_baseline(ns_sample=16):
+    import numpy as np  # noqa: F401
+    from oracle import MODE_REF_POOL, OracleScene
+
+    threads = min(16, os.cpu_count() or 1)
+    osc = OracleScene.build(1, NX, NY, seed=SEED)
+    state = osc.rng_after()
+    t0 = time.perf_counter()
+    _, _, ctr = osc.render(NX, NY, ns_sample, seed=SEED, mode=MODE_REF_POOL, threads=threads, state=state, pow5_mode=1)
+    dt = time.perf_counter() - t0
+    return {"value": round(ctr["rays"] / dt / 1e6, 2), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"chap12 {NX}x{NY}, {ns_sample} of {NS} spp, depth {MAX_DEPTH}, seed {SEED}: {ctr['rays']} rays in {dt:.2f} s; "
+                      "C restatement of the reference CPU path (per-thread jumped Xoshiro128+, dynamic pixel scheduling), scene build excluded"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp", type=int, default=NS, help="samples per pixel per GPU (the headline workload is 500)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import rrt_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    ctx = rrt_amd.Context(local_rank)
+    scene = rrt_amd.HostScene(rrt_amd.SCENE_CHAP12, NX, NY, seed=SEED)
+    ctx.upload_host_scene(scene)
+
+    ns_total = args.spp * world
+    accum = torch.zeros(NY * NX * 3, dtype=torch.float32, device=dev)
+    rgb8 = torch.zeros(NY * NX * 3, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+
+    def params(count=False, timed=False):
+        if world == 1:
+            return rrt_amd.Context.params(NX, NY, ns_total, seed=SEED, max_depth=MAX_DEPTH, count_work=count, time_kernels=timed)
+        return rrt_amd.Context.params(NX, NY, ns_total, seed=SEED, max_depth=MAX_DEPTH, shard_mode=rrt_amd.SHARD_SAMPLE, rank=rank,
+                                      world=world, count_work=count, time_kernels=timed)
+
+    def step(count=False, timed=False):
+        if world == 1:
+            return ctx.render_device(params(count, timed), rgb8.data_ptr(), accum.data_ptr())
+        st = ctx.render_device(params(count, timed), 0, accum.data_ptr())
+        dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)      # framebuffer combine over xGMI
+        if rank == 0:
+            torch.cuda.synchronize()
+            ctx.finalize(accum.data_ptr(), NX * NY, ns_total, rgb8.data_ptr())
+        return st
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    rays_local = 0
+    ext_ms = 0.0
+    ext_launches = 0
+    gpu_ms = 0.0
+    for _ in range(args.steps):
+        st = step(timed=not args.no_roofline)
+        rays_local += st["rays"]
+        ext_ms += st["extend_ms"]
+        ext_launches += st["extend_launches"]
+        gpu_ms += st["gpu_ms"]
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        r = torch.tensor([rays_local], dtype=torch.int64, device=dev)
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        rays_total = int(r.item())
+    else:
+        rays_total = rays_local
+
+    roofline = None
+    if not args.no_roofline and rank == 0:
+        # Work counters come from one more pass of the counting build of the same kernels on the same seeds
+        # (deterministic); launch durations come from HIP events around every extend launch of the timed steps.
+        cst = step(count=True)
+        flops = extend_flops(cst) * args.steps
+        byts = extend_bytes(cst) * args.steps
+        achieved = flops / (ext_ms * 1e-3) / 1e12 if ext_ms > 0 else 0.0
+        roofline = {
+            "kernel": "k_extend", "bound": "valu_fp32", "achieved": round(achieved, 3), "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / FP32_VECTOR_PEAK_TFLOPS, 4), "traffic": None,
+            "launches": ext_launches, "avg_launch_ms": round(ext_ms / max(1, ext_launches), 4),
+            "flop_per_launch": round(flops / max(1, ext_launches)),
+            "hbm": {"achieved": round(byts / (ext_ms * 1e-3) / 1e9, 1) if ext_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(byts / (ext_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ext_ms > 0 else 0.0},
+            "extend_share_of_gpu_time": round(ext_ms / gpu_ms, 3) if gpu_ms > 0 else None,
+            "per_ray": {"inner_visits": round(cst["inner_visits"] / cst["rays"], 2), "leaf_tests": round(cst["leaf_tests"] / cst["rays"], 2),
+                        "rays_per_path": round(cst["rays"] / cst["paths"], 3)},
+        }
+    elif world > 1:
+        step(count=False)  # keep every rank in the collective of rank 0's extra pass
+    if world > 1 and not args.no_roofline and rank != 0:
+        pass
+
+    if rank == 0:
+        out = {
+            "metric": "Mrays/s (paths x bounces), chap12 scene", "value": round(rays_total / elapsed / 1e6, 1), "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"chap12 random-spheres scene seed {SEED} (484 spheres, 967 BVH nodes), {NX}x{NY}, "
+                                   f"{args.spp} spp per GPU ({ns_total} spp total), max depth {MAX_DEPTH}",
+                       "sharding": "none" if world == 1 else f"sample shards, f32 framebuffer reduce over RCCL ({world} ranks)",
+                       "rays_per_step": rays_total // max(1, args.steps)},
+            "device": ctx.device_info()["name"],
+        }
+        if roofline is not None:
+            out["roofline"] = roofline
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
