@@ -256,12 +256,13 @@ class Context:
     @staticmethod
     def params(nx: int, ny: int, ns: int, seed: int = 0, max_depth: int = 50, shard_mode: int = SHARD_NONE, rank: int = 0,
                world: int = 1, count_work: bool = False, path_slots: int = 0, batch_samples: int = 0,
-               time_kernels: bool = False) -> RenderParams:
+               time_kernels: bool = False, force_hbm_bvh: bool = False) -> RenderParams:
         p = RenderParams()
         p.nx, p.ny, p.ns, p.max_depth, p.seed = nx, ny, ns, max_depth, seed
         p.shard_mode, p.shard_rank, p.shard_world = shard_mode, rank, world
         p.count_work, p.path_slots, p.batch_samples = int(count_work), path_slots, batch_samples
         p.reserved[0] = int(time_kernels)
+        p.reserved[1] = int(force_hbm_bvh)
         return p
 
     def render(self, p: RenderParams, want_accum: bool = True) -> Tuple[np.ndarray, Optional[np.ndarray], dict]:

@@ -56,7 +56,7 @@ struct rrt_ctx {
     hipStream_t stream = nullptr;
     hipDeviceProp_t prop{};
     // scene
-    DevBuf nodes, sph, motion, motion_dt, sph_info, mat, prim_att;
+    DevBuf nodes, small_nodes, sph, motion, motion_dt, sph_info, mat, prim_att;
     SceneDev sd{};
     bool has_scene = false, moving = false;
     uint32_t n_spheres = 0, n_nodes = 0;
@@ -104,7 +104,7 @@ void rrt_destroy(rrt_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->nodes, &c->sph, &c->motion, &c->motion_dt, &c->sph_info, &c->mat, &c->prim_att, &c->rayA, &c->rayB, &c->rng,
+    for (DevBuf *b : {&c->nodes, &c->small_nodes, &c->sph, &c->motion, &c->motion_dt, &c->sph_info, &c->mat, &c->prim_att, &c->rayA, &c->rayB, &c->rng,
                       &c->depth, &c->hit, &c->trail, &c->queue, &c->qcount, &c->wave_stats, &c->cursors, &c->flags, &c->stats_out,
                       &c->accum, &c->rad, &c->pixel_map, &c->tmp_rgb, &c->tmp_acc, &c->q_org, &c->q_dir, &c->q_time, &c->q_t, &c->q_obj})
         b->release();
@@ -139,6 +139,7 @@ int rrt_upload_scene(rrt_ctx *c, const rrt_sphere_soa *sp, const rrt_material_so
         return bytes ? hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream) : hipSuccess;
     };
     HIP_TRY(up(c->nodes, L.nodes.data(), L.nodes.size() * 4));
+    HIP_TRY(up(c->small_nodes, L.small_nodes.data(), L.small_nodes.size() * 4));
     HIP_TRY(up(c->sph, L.sph.data(), L.sph.size() * sizeof(Float4)));
     HIP_TRY(up(c->motion, L.motion.data(), L.motion.size() * sizeof(Float4)));
     HIP_TRY(up(c->motion_dt, L.motion_dt.data(), L.motion_dt.size() * 4));
@@ -157,6 +158,10 @@ int rrt_upload_scene(rrt_ctx *c, const rrt_sphere_soa *sp, const rrt_material_so
     c->sd.flags = L.flags;
     c->sd.u_time0 = L.u_time0;
     c->sd.u_dt = L.u_dt;
+    c->sd.small_nodes = L.small_nodes.empty() ? nullptr : c->small_nodes.as<uint4>();
+    c->sd.small_words = L.small_words;
+    c->sd.small_root = L.small_root;
+    c->sd.n_nodes = L.n_nodes;
     c->moving = (L.flags & kSceneHasMoving) != 0;
     c->n_spheres = L.n_spheres;
     c->n_nodes = L.n_nodes;
@@ -235,6 +240,8 @@ int render_impl(rrt_ctx *c, const rrt_render_params *pp, void *d_rgb8, void *d_a
     uint32_t n_waves = 0;
     size_t kev_used = 0;
     const bool count = P.count_work != 0;
+    SceneDev sd = c->sd;
+    if (P.reserved[1] & 1u) sd.small_nodes = nullptr;  // walk the HBM copy of the BVH even if the scene fits in LDS
     const bool time_kernels = count || P.reserved[0] != 0;
     if (npix > 0 && ns_local > 0) {
         // ---- batch and slot sizing ----
@@ -286,10 +293,10 @@ int render_impl(rrt_ctx *c, const rrt_render_params *pp, void *d_rgb8, void *d_a
                         while (c->kev.size() < kev_used + 2) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); c->kev.push_back(ev); }
                         HIP_TRY(hipEventRecord(c->kev[kev_used], s));
                     }
-                    launch_extend(s, c->sd, ps, c->moving, count, wstats);
+                    launch_extend(s, sd, ps, c->moving, count, wstats);
                     if (time_kernels) { HIP_TRY(hipEventRecord(c->kev[kev_used + 1], s)); kev_used += 2; }
                     bd.alive_flag = flags + it;
-                    launch_shade(s, c->sd, ps, bd, c->cam, c->moving, count, wstats);
+                    launch_shade(s, sd, ps, bd, c->cam, c->moving, count, wstats);
                 }
                 st.iterations += kChunk;
                 HIP_TRY(hipGetLastError());

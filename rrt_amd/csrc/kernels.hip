@@ -204,6 +204,107 @@ __global__ __launch_bounds__(kBlockThreads) void k_extend(SceneDev S, PathState 
     if (lane == 0) st[ST_RAYS] += count;
 }
 
+// The same walk over the compact node copy held in LDS (16-bit references, scene_layout.h).  `best` receives the
+// node index of the closest leaf; the caller turns it into a sphere index with one more LDS read.
+template <bool MOVING, bool COUNT>
+DEV void traverse_lds(const uint4 *lds4, uint32_t root16, const SceneDev &S, V3 o, V3 d, float time, float tmin, float &tmax,
+                      uint32_t &best_node, uint32_t &n_inner, uint32_t &n_leaf) {
+    constexpr uint32_t W = MOVING ? kSmallWordsMoving : kSmallWordsStatic;
+    const uint16_t *lds16 = reinterpret_cast<const uint16_t *>(lds4);
+    const uint32_t *lds32 = reinterpret_cast<const uint32_t *>(lds4);
+    const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const bool ngx = inv.x < 0.0f, ngy = inv.y < 0.0f, ngz = inv.z < 0.0f;
+    const uint32_t oct = (ngx ? 1u : 0u) | (ngy ? 2u : 0u) | (ngz ? 4u : 0u);
+    const float a = dot3(d, d);
+    float f_ray = 0.0f;
+    if (MOVING) f_ray = (time - S.u_time0) / S.u_dt;  // the compact copy exists only when all moving spheres share their shutter interval
+    uint32_t cur = root16;
+    while (cur != kRef16End) {
+        const uint32_t idx = cur & (kRef16LeafBit - 1u);
+        const uint4 n0 = lds4[idx * (W / 4u)];
+        if (cur & kRef16LeafBit) {
+            if (COUNT) n_leaf++;
+            V3 c = mk(u2f(n0.x), u2f(n0.y), u2f(n0.z));
+            const float rr = u2f(n0.w);
+            if (MOVING) {
+                if (lds32[idx * W + 5u] & 1u) {
+                    const uint4 m = lds4[idx * (W / 4u) + 3u];
+                    c = add(c, scale(f_ray, mk(u2f(m.x), u2f(m.y), u2f(m.z))));
+                }
+            }
+            const V3 oc = sub(o, c);
+            const float half_b = dot3(oc, d);
+            const float cc = dot3(oc, oc) - rr;
+            const float disc = (half_b * half_b) - (a * cc);
+            if (!(disc < 0.0f)) {
+                const float sq = sqrtf(disc);
+                float root = (-half_b - sq) / a;
+                bool outside = root < tmin || tmax < root;
+                if (outside) {
+                    root = (-half_b + sq) / a;
+                    outside = root < tmin || tmax < root;
+                }
+                if (!outside) { tmax = root; best_node = idx; }
+            }
+            cur = lds16[idx * (W * 2u) + 16u + oct];
+        } else {
+            if (COUNT) n_inner++;
+            const uint4 n1 = lds4[idx * (W / 4u) + 1u];
+            const float lox = u2f(n0.x), loy = u2f(n0.y), loz = u2f(n0.z), hix = u2f(n0.w), hiy = u2f(n1.x), hiz = u2f(n1.y);
+            const float tnx = ((ngx ? hix : lox) - o.x) * inv.x;
+            const float tny = ((ngy ? hiy : loy) - o.y) * inv.y;
+            const float tnz = ((ngz ? hiz : loz) - o.z) * inv.z;
+            const float tfx = (((ngx ? lox : hix) - o.x) * inv.x) * RRT_FAR_SCALE;
+            const float tfy = (((ngy ? loy : hiy) - o.y) * inv.y) * RRT_FAR_SCALE;
+            const float tfz = (((ngz ? loz : hiz) - o.z) * inv.z) * RRT_FAR_SCALE;
+            const float t0 = fmaxf(fmaxf(fmaxf(tnx, tny), tnz), tmin);
+            const float t1 = fminf(fminf(fminf(tfx, tfy), tfz), tmax);
+            if (t0 <= t1) {
+                const bool neg_axis = (oct >> n1.w) & 1u;
+                cur = neg_axis ? (n1.z >> 16) : (n1.z & 0xFFFFu);
+            } else {
+                cur = lds16[idx * (W * 2u) + 16u + oct];
+            }
+        }
+    }
+}
+
+constexpr uint32_t kLdsBlockThreads = 1024;  // 16 waves share one LDS copy of the scene
+
+template <bool MOVING, bool COUNT>
+__global__ __launch_bounds__(kLdsBlockThreads) void k_extend_lds(SceneDev S, PathState P, uint64_t *wave_stats) {
+    extern __shared__ uint4 lds4[];
+    constexpr uint32_t W = MOVING ? kSmallWordsMoving : kSmallWordsStatic;
+    const uint32_t n_vec = S.n_nodes * (W / 4u);
+    for (uint32_t i = threadIdx.x; i < n_vec; i += kLdsBlockThreads) lds4[i] = S.small_nodes[i];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * kLdsBlockThreads + threadIdx.x) >> 6;
+    const uint32_t base = wave * kWaveSlots;
+    if (base >= P.n_slots) return;
+    const uint32_t count = rfl(P.qcount[wave]);
+    if (count == 0) return;
+    const uint32_t *lds32 = reinterpret_cast<const uint32_t *>(lds4);
+    uint32_t n_inner = 0, n_leaf = 0;
+    for (uint32_t i = lane; i < count; i += 64u) {
+        const uint32_t slot = P.queue[base + i];
+        const float4 A = P.rayA[slot];
+        const float4 B = P.rayB[slot];
+        float tmax = __FLT_MAX__;
+        uint32_t best_node = kPrimNone;
+        traverse_lds<MOVING, COUNT>(lds4, S.small_root, S, mk(A.x, A.y, A.z), mk(B.x, B.y, B.z), A.w, 0.001f, tmax, best_node, n_inner,
+                                    n_leaf);
+        const uint32_t best = best_node == kPrimNone ? kPrimNone : lds32[best_node * W + 4u];
+        P.hit[slot] = make_uint2(f2u(tmax), best);
+    }
+    uint64_t *st = wave_stats + (size_t)wave * kWaveStatWords;
+    if (COUNT) {
+        const uint64_t si = wave_sum_u64(n_inner), sl = wave_sum_u64(n_leaf);
+        if (lane == 0) { st[ST_INNER] += si; st[ST_LEAF] += sl; }
+    }
+    if (lane == 0) st[ST_RAYS] += count;
+}
+
 // (1 - cos)^5 of materials.rs:68, as a double-precision product rounded once to f32
 DEV float pow5(float x) { const double d = (double)x, d2 = d * d, d4 = d2 * d2; return (float)(d4 * d); }
 DEV float reflectance(float cosine, float ref_idx) {  // materials.rs:65-69
@@ -478,6 +579,19 @@ void launch_raygen(hipStream_t s, const PathState &P, const BatchDev &B, const C
 }
 
 void launch_extend(hipStream_t s, const SceneDev &S, const PathState &P, bool moving, bool count, uint64_t *wave_stats) {
+    if (S.small_nodes) {  // scene fits in LDS
+        const uint32_t waves_per_block = kLdsBlockThreads / 64u;
+        const dim3 g((P.n_slots / kWaveSlots + waves_per_block - 1u) / waves_per_block), b(kLdsBlockThreads);
+        const size_t lds = (size_t)S.n_nodes * S.small_words * 4u;
+        if (moving) {
+            if (count) hipLaunchKernelGGL((k_extend_lds<true, true>), g, b, lds, s, S, P, wave_stats);
+            else hipLaunchKernelGGL((k_extend_lds<true, false>), g, b, lds, s, S, P, wave_stats);
+        } else {
+            if (count) hipLaunchKernelGGL((k_extend_lds<false, true>), g, b, lds, s, S, P, wave_stats);
+            else hipLaunchKernelGGL((k_extend_lds<false, false>), g, b, lds, s, S, P, wave_stats);
+        }
+        return;
+    }
     const dim3 g(wave_grid(P)), b(kBlockThreads);
     if (moving) {
         if (count) hipLaunchKernelGGL((k_extend<true, true>), g, b, 0, s, S, P, wave_stats);

@@ -138,6 +138,33 @@ int build_scene_layout(const rrt_sphere_soa *sp, const rrt_material_soa *mt, con
             ls.push_back({near_i, ref_of(far_i)});
         }
     }
+
+    // ---- compact copy for LDS residency: 16-bit references, 48 or 64 bytes per node ----
+    const bool moving = (out.flags & kSceneHasMoving) != 0;
+    const uint32_t sw = moving ? kSmallWordsMoving : kSmallWordsStatic;
+    const bool times_ok = !moving || (out.flags & kSceneUniformTimes) != 0;
+    if (times_ok && n_nodes < kRef16End && static_cast<size_t>(n_nodes) * sw * 4 <= kSmallLdsBudget) {
+        auto ref16 = [&](uint32_t r) -> uint32_t {
+            if (r == kRefEnd) return kRef16End;
+            return (r & kRefIndexMask) | ((r & kRefLeafBit) ? kRef16LeafBit : 0u);
+        };
+        out.small_words = sw;
+        out.small_nodes.assign(static_cast<size_t>(n_nodes) * sw, 0u);
+        for (uint32_t i = 0; i < n_nodes; i++) {
+            const uint32_t *w = &out.nodes[static_cast<size_t>(i) * kNodeWords];
+            uint32_t *s = &out.small_nodes[static_cast<size_t>(i) * sw];
+            for (int k = 0; k < 6; k++) s[k] = w[k];
+            if (!is_leaf(nodes[i])) {
+                s[6] = ref16(w[7]) | (ref16(w[6] & (kRefLeafBit | kRefIndexMask)) << 16);
+                s[7] = (w[6] >> RRT_NODE_AXIS_SHIFT) & 3u;
+            } else if (moving && (w[5] & 1u)) {
+                const Float4 &m = out.motion[w[4]];
+                s[12] = f2u(m.x); s[13] = f2u(m.y); s[14] = f2u(m.z);
+            }
+            for (int o = 0; o < 8; o += 2) s[8 + o / 2] = ref16(w[8 + o]) | (ref16(w[8 + o + 1]) << 16);
+        }
+        out.small_root = ref16(out.root_ref);
+    }
     return RRT_OK;
 }
 

@@ -20,6 +20,13 @@ constexpr uint32_t kRefEnd = 0x7FFFFFFFu;       // "nothing left to visit"
 constexpr uint32_t kRefIndexMask = 0x1FFFFFFFu; // node index inside a reference
 constexpr uint32_t kNodeWords = 16;             // 64 bytes
 
+// Compact layout for scenes small enough to live in a workgroup's LDS: 16-bit references.
+constexpr uint32_t kRef16LeafBit = 0x8000u;
+constexpr uint32_t kRef16End = 0x7FFFu;
+constexpr uint32_t kSmallWordsStatic = 12;   // 48 bytes per node
+constexpr uint32_t kSmallWordsMoving = 16;   // 64 bytes per node: + centre1 - centre0
+constexpr uint32_t kSmallLdsBudget = 64u * 1024u;
+
 // Per-sphere info word: material index | kind << 28 | moving << 31
 constexpr uint32_t kInfoMatMask = 0x0FFFFFFFu;
 constexpr uint32_t kInfoKindShift = 28;
@@ -39,6 +46,13 @@ struct SceneLayout {
     uint32_t n_nodes = 0;
     uint32_t root_ref = kRefEnd;
     uint32_t max_leaf_depth = 0;
+
+    // Compact node words (empty when the scene does not qualify).  [0..3] inner: min xyz, max x; leaf: centre,
+    // radius^2.  [4..5] inner: max y, max z; leaf: sphere index, moving flag.  [6] inner: left ref16 | right
+    // ref16 << 16.  [7] inner: axis.  [8..11] eight 16-bit exit links.  [12..14] (moving scenes) centre1 - centre0.
+    std::vector<uint32_t> small_nodes;
+    uint32_t small_words = 0;
+    uint32_t small_root = kRef16End;
 
     std::vector<Float4> sph;        // {centre at time0, radius}
     std::vector<Float4> motion;     // {centre1 - centre0, time0}

@@ -117,6 +117,19 @@ def test_depth_limit(gpu_ctx, max_depth):
     assert_same_image(gpu, ref)
 
 
+@pytest.mark.parametrize("name", list(SCENES))
+def test_lds_walk_and_hbm_walk_agree(gpu_ctx, name):
+    """Small scenes are walked from an LDS copy of the BVH, large ones from HBM: same kernels otherwise, same bits."""
+    nx, ny, ns = 96, 64, 8
+    osc = OracleScene.build(SCENES[name], nx, ny, seed=0)
+    upload_from_oracle(gpu_ctx, osc)
+    ref = osc.render(nx, ny, ns, seed=21, threads=8)
+    for force_hbm in (False, True):
+        gpu = gpu_ctx.render(rrt_amd.Context.params(nx, ny, ns, seed=21, force_hbm_bvh=force_hbm, count_work=True))
+        assert_same_image(gpu, ref)
+        assert gpu[2]["inner_visits"] == ref[2]["inner_visits"] and gpu[2]["leaf_tests"] == ref[2]["leaf_tests"]
+
+
 def test_schedule_independence(gpu_ctx):
     """Slots in flight and batch size change the schedule, never a bit of the result."""
     nx, ny, ns = 80, 50, 12
