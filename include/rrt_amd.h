@@ -128,6 +128,7 @@ typedef struct rrt_stats {
     double   gpu_ms;       /* device time of the whole call between HIP events */
     double   extend_ms;    /* summed device time of the extend kernel launches (count_work or timing enabled) */
     uint64_t extend_launches;
+    uint64_t debug[6];     /* count_work only: extend descent passes, lanes in them, sphere-test passes, lanes in them, retire passes, lanes */
 } rrt_stats;
 
 typedef struct rrt_ctx rrt_ctx;
@@ -176,7 +177,7 @@ RRT_API int rrt_validate_scene(const rrt_sphere_soa *spheres, const rrt_material
                                uint32_t n_nodes);
 
 /* Host-only: the traversal layout rrt_upload_scene would copy to the GPU.  words16: n_nodes x 16 uint32
- * (inner: box min xyz, max xyz, right ref | axis << 29, left ref, 8 exit links; leaf: centre xyz, radius^2,
+ * (inner: box as (min, max) pairs for x, y, z, right ref | axis << 29, left ref, 8 exit links; leaf: centre xyz, radius^2,
  * sphere index, moving flag, 0, 0, 8 exit links).  A ref is a node index, bit 31 set for a leaf,
  * 0x7FFFFFFF for "traversal finished".  For inspection and for tests of the link construction. */
 RRT_API int rrt_debug_layout(const rrt_sphere_soa *spheres, const rrt_material_soa *materials, const rrt_bvh_node *nodes,

@@ -70,10 +70,13 @@ class RenderParams(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "rays", "inner_visits", "leaf_tests", "hits_lambertian", "hits_metal", "hits_dielectric", "sky_misses", "paths",
-        "depth_cut", "absorbed", "iterations")] + [("gpu_ms", C.c_double), ("extend_ms", C.c_double), ("extend_launches", C.c_uint64)]
+        "depth_cut", "absorbed", "iterations")] + [("gpu_ms", C.c_double), ("extend_ms", C.c_double), ("extend_launches", C.c_uint64),
+                                                 ("debug", C.c_uint64 * 6)]
 
     def as_dict(self) -> dict:
-        return {n: getattr(self, n) for n, _ in self._fields_}
+        d = {n: getattr(self, n) for n, _ in self._fields_}
+        d["debug"] = list(self.debug)
+        return d
 
 
 _lib = None
@@ -256,13 +259,15 @@ class Context:
     @staticmethod
     def params(nx: int, ny: int, ns: int, seed: int = 0, max_depth: int = 50, shard_mode: int = SHARD_NONE, rank: int = 0,
                world: int = 1, count_work: bool = False, path_slots: int = 0, batch_samples: int = 0,
-               time_kernels: bool = False, force_hbm_bvh: bool = False) -> RenderParams:
+               time_kernels: bool = False, force_hbm_bvh: bool = False, retire_min: int = 0, leaf_min: int = 0) -> RenderParams:
         p = RenderParams()
         p.nx, p.ny, p.ns, p.max_depth, p.seed = nx, ny, ns, max_depth, seed
         p.shard_mode, p.shard_rank, p.shard_world = shard_mode, rank, world
         p.count_work, p.path_slots, p.batch_samples = int(count_work), path_slots, batch_samples
         p.reserved[0] = int(time_kernels)
         p.reserved[1] = int(force_hbm_bvh)
+        p.reserved[2] = int(retire_min)
+        p.reserved[3] = int(leaf_min)
         return p
 
     def render(self, p: RenderParams, want_accum: bool = True) -> Tuple[np.ndarray, Optional[np.ndarray], dict]:

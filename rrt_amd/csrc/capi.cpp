@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -46,24 +47,26 @@ struct DevBuf {
 constexpr uint32_t kDefaultSlots = 1u << 21;
 constexpr size_t kRadBudgetBytes = size_t(3) << 30;
 constexpr uint32_t kMaxBatchPaths = 1u << 30;
+constexpr uint32_t kFlagWords = 2 * 32 * 32;  // per half: 32 flag words, one per 128-byte line
 constexpr uint32_t kChunk = 8;  // extend+shade rounds queued between two looks at the alive flag
-constexpr uint32_t kMaxDepthLimit = 4096;
+constexpr uint32_t kMaxDepthLimit = 4096;  // depth and trail length share one 32-bit word per path
 
 }  // namespace
 
 struct rrt_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_ext[2] = {nullptr, nullptr}, ev_shd[2] = {nullptr, nullptr};
     hipDeviceProp_t prop{};
     // scene
-    DevBuf nodes, small_nodes, sph, motion, motion_dt, sph_info, mat, prim_att;
+    DevBuf nodes, small_nodes, sph, motion, motion_dt, sph_info, mat, pmat, prim_att;
     SceneDev sd{};
     bool has_scene = false, moving = false;
     uint32_t n_spheres = 0, n_nodes = 0;
     CameraDev cam{};
     bool has_cam = false;
     // path state
-    DevBuf rayA, rayB, rng, depth, hit, trail, queue, qcount, wave_stats, cursors, flags, stats_out;
+    DevBuf rayA, rayB, rayC, recent, rng, depth, hit, trail, queue, qcount, wave_stats, cursors, flags, stats_out;
     DevBuf accum, rad, pixel_map, tmp_rgb, tmp_acc;
     uint32_t *h_flags = nullptr;   // pinned
     uint64_t *h_stats = nullptr;   // pinned
@@ -90,7 +93,14 @@ int rrt_create(int device, rrt_ctx **out) {
     rrt_ctx *c = new rrt_ctx();
     c->device = device;
     if (hipGetDeviceProperties(&c->prop, device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void **>(&c->h_flags), sizeof(uint32_t) * 64, hipHostMallocDefault) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_ext[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_ext[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_shd[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_shd[1], hipEventDisableTiming) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **>(&c->h_flags), sizeof(uint32_t) * kFlagWords, hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&c->h_stats), sizeof(uint64_t) * kWaveStatWords, hipHostMallocDefault) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
         rrt_destroy(c);
@@ -104,7 +114,8 @@ void rrt_destroy(rrt_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->nodes, &c->small_nodes, &c->sph, &c->motion, &c->motion_dt, &c->sph_info, &c->mat, &c->prim_att, &c->rayA, &c->rayB, &c->rng,
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    for (DevBuf *b : {&c->nodes, &c->small_nodes, &c->sph, &c->motion, &c->motion_dt, &c->sph_info, &c->mat, &c->pmat, &c->prim_att, &c->rayA, &c->rayB, &c->rayC, &c->recent, &c->rng,
                       &c->depth, &c->hit, &c->trail, &c->queue, &c->qcount, &c->wave_stats, &c->cursors, &c->flags, &c->stats_out,
                       &c->accum, &c->rad, &c->pixel_map, &c->tmp_rgb, &c->tmp_acc, &c->q_org, &c->q_dir, &c->q_time, &c->q_t, &c->q_obj})
         b->release();
@@ -113,6 +124,10 @@ void rrt_destroy(rrt_ctx *c) {
     if (c->h_stats) (void)hipHostFree(c->h_stats);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (hipEvent_t ev : {c->ev_ext[0], c->ev_ext[1], c->ev_shd[0], c->ev_shd[1]}) if (ev) (void)hipEventDestroy(ev);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -146,6 +161,7 @@ int rrt_upload_scene(rrt_ctx *c, const rrt_sphere_soa *sp, const rrt_material_so
     HIP_TRY(up(c->sph_info, L.sph_info.data(), L.sph_info.size() * 4));
     HIP_TRY(up(c->mat, L.mat.data(), L.mat.size() * sizeof(Float4)));
     HIP_TRY(up(c->prim_att, L.prim_att.data(), L.prim_att.size() * sizeof(Float4)));
+    HIP_TRY(up(c->pmat, L.pmat.data(), L.pmat.size() * sizeof(Float4)));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->sd.nodes = c->nodes.as<uint4>();
     c->sd.root_ref = L.root_ref;
@@ -154,6 +170,7 @@ int rrt_upload_scene(rrt_ctx *c, const rrt_sphere_soa *sp, const rrt_material_so
     c->sd.motion_dt = c->motion_dt.as<float>();
     c->sd.sph_info = c->sph_info.as<uint32_t>();
     c->sd.mat = c->mat.as<float4>();
+    c->sd.pmat = c->pmat.as<float4>();
     c->sd.prim_att = c->prim_att.as<float4>();
     c->sd.flags = L.flags;
     c->sd.u_time0 = L.u_time0;
@@ -240,6 +257,8 @@ int render_impl(rrt_ctx *c, const rrt_render_params *pp, void *d_rgb8, void *d_a
     uint32_t n_waves = 0;
     size_t kev_used = 0;
     const bool count = P.count_work != 0;
+    const uint32_t retire_min = P.reserved[2] ? std::min<uint32_t>(P.reserved[2], 64u) : 16u;  // tuning knob of the extend kernel
+    const uint32_t leaf_min = P.reserved[3] ? std::min<uint32_t>(P.reserved[3], 64u) : 16u;
     SceneDev sd = c->sd;
     if (P.reserved[1] & 1u) sd.small_nodes = nullptr;  // walk the HBM copy of the BVH even if the scene fits in LDS
     const bool time_kernels = count || P.reserved[0] != 0;
@@ -255,22 +274,32 @@ int render_impl(rrt_ctx *c, const rrt_render_params *pp, void *d_rgb8, void *d_a
         n_waves = slots / kWaveSlots;
         const uint32_t trail_levels = std::max<uint32_t>(1, P.max_depth);
 
-        HIP_TRY(c->rayA.ensure((size_t)slots * 16)); HIP_TRY(c->rayB.ensure((size_t)slots * 16));
+        HIP_TRY(c->rayA.ensure((size_t)slots * 16)); HIP_TRY(c->rayB.ensure((size_t)slots * 16)); HIP_TRY(c->rayC.ensure((size_t)slots * 16)); HIP_TRY(c->recent.ensure((size_t)slots * 16));
         HIP_TRY(c->rng.ensure((size_t)slots * 16)); HIP_TRY(c->depth.ensure((size_t)slots * 4));
         HIP_TRY(c->hit.ensure((size_t)slots * 8)); HIP_TRY(c->trail.ensure((size_t)slots * 4 * trail_levels));
         HIP_TRY(c->queue.ensure((size_t)slots * 4)); HIP_TRY(c->qcount.ensure((size_t)n_waves * 4));
         HIP_TRY(c->wave_stats.ensure((size_t)n_waves * kWaveStatWords * 8));
         HIP_TRY(c->cursors.ensure((size_t)kCursorShards * kCursorStride * 4));
-        HIP_TRY(c->flags.ensure(64 * 4)); HIP_TRY(c->stats_out.ensure(kWaveStatWords * 8));
+        HIP_TRY(c->flags.ensure(kFlagWords * 4)); HIP_TRY(c->stats_out.ensure(kWaveStatWords * 8));
         HIP_TRY(c->accum.ensure((size_t)npix * 12)); HIP_TRY(c->rad.ensure((size_t)rad_plane * 12));
 
         PathState ps{};
-        ps.rayA = c->rayA.as<float4>(); ps.rayB = c->rayB.as<float4>(); ps.rng = c->rng.as<uint4>();
+        ps.rayA = c->rayA.as<float4>(); ps.rayB = c->rayB.as<float4>(); ps.rayC = c->rayC.as<float4>(); ps.recent = c->recent.as<uint4>(); ps.rng = c->rng.as<uint4>();
         ps.depth = c->depth.as<uint32_t>(); ps.hit = c->hit.as<uint2>(); ps.trail = c->trail.as<uint32_t>();
-        ps.queue = c->queue.as<uint32_t>(); ps.qcount = c->qcount.as<uint32_t>(); ps.n_slots = slots;
+        ps.queue = c->queue.as<uint32_t>(); ps.qcount = c->qcount.as<uint32_t>(); ps.n_slots = slots; ps.trail_levels = trail_levels;
+        ps.wave_begin = 0; ps.wave_end = n_waves;
         uint64_t *wstats = c->wave_stats.as<uint64_t>();
         HIP_TRY(hipMemsetAsync(wstats, 0, (size_t)n_waves * kWaveStatWords * 8, s));
         uint32_t *flags = c->flags.as<uint32_t>();
+
+        // The path pool is worked on in two halves.  All extend launches go to one stream and all shade launches to a
+        // second one, chained by events (extend(h) -> shade(h) -> next extend(h)), so that the extend kernel of one half
+        // (VALU-bound) always runs beside the shade kernel of the other half (bound by memory latency).
+        const char *env_streams = std::getenv("RRT_STREAMS");
+        const uint32_t n_half = (n_waves >= 64 && !(env_streams && env_streams[0] == '1')) ? 2u : 1u;
+        hipStream_t s_ext = s, s_shd = n_half == 2 ? c->stream2 : s;
+        PathState half[2] = {ps, ps};
+        if (n_half == 2) { half[0].wave_end = n_waves / 2; half[1].wave_begin = n_waves / 2; }
 
         for (uint32_t s0 = 0; s0 < ns_local; s0 += batch) {
             const uint32_t nb = std::min(batch, ns_local - s0);
@@ -283,26 +312,35 @@ int render_impl(rrt_ctx *c, const rrt_render_params *pp, void *d_rgb8, void *d_a
             bd.max_depth = P.max_depth;
             bd.cursors = c->cursors.as<uint32_t>();
             bd.n_shards = std::min(kCursorShards, n_waves);
-            bd.alive_flag = flags + kChunk;  // raygen's mark is not looked at
+            bd.alive_flag = nullptr;  // raygen's survivors are not looked at
             HIP_TRY(hipMemsetAsync(bd.cursors, 0, (size_t)kCursorShards * kCursorStride * 4, s));
             launch_raygen(s, ps, bd, c->cam, wstats);
             for (;;) {
-                HIP_TRY(hipMemsetAsync(flags, 0, 64 * 4, s));
+                HIP_TRY(hipMemsetAsync(flags, 0, kFlagWords * 4, s));
+                if (n_half == 2) { HIP_TRY(hipEventRecord(c->ev_fork, s)); HIP_TRY(hipStreamWaitEvent(s_shd, c->ev_fork, 0)); }
                 for (uint32_t it = 0; it < kChunk; it++) {
-                    if (time_kernels) {
-                        while (c->kev.size() < kev_used + 2) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); c->kev.push_back(ev); }
-                        HIP_TRY(hipEventRecord(c->kev[kev_used], s));
+                    for (uint32_t h = 0; h < n_half; h++) {
+                        if (n_half == 2 && it > 0) HIP_TRY(hipStreamWaitEvent(s_ext, c->ev_shd[h], 0));  // the half's previous shade
+                        if (time_kernels) {
+                            while (c->kev.size() < kev_used + 2) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); c->kev.push_back(ev); }
+                            HIP_TRY(hipEventRecord(c->kev[kev_used], s_ext));
+                        }
+                        launch_extend(s_ext, sd, half[h], c->moving, count, retire_min, leaf_min, wstats);
+                        if (time_kernels) { HIP_TRY(hipEventRecord(c->kev[kev_used + 1], s_ext)); kev_used += 2; }
+                        if (n_half == 2) { HIP_TRY(hipEventRecord(c->ev_ext[h], s_ext)); HIP_TRY(hipStreamWaitEvent(s_shd, c->ev_ext[h], 0)); }
+                        bd.alive_flag = it + 1 == kChunk ? flags + h * 1024 : nullptr;  // only the chunk's last round reports
+                        launch_shade(s_shd, sd, half[h], bd, c->cam, c->moving, count, wstats);
+                        if (n_half == 2) HIP_TRY(hipEventRecord(c->ev_shd[h], s_shd));
                     }
-                    launch_extend(s, sd, ps, c->moving, count, wstats);
-                    if (time_kernels) { HIP_TRY(hipEventRecord(c->kev[kev_used + 1], s)); kev_used += 2; }
-                    bd.alive_flag = flags + it;
-                    launch_shade(s, sd, ps, bd, c->cam, c->moving, count, wstats);
                 }
                 st.iterations += kChunk;
                 HIP_TRY(hipGetLastError());
-                HIP_TRY(hipMemcpyAsync(c->h_flags, flags, kChunk * 4, hipMemcpyDeviceToHost, s));
+                if (n_half == 2) { HIP_TRY(hipEventRecord(c->ev_join, s_shd)); HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0)); }
+                HIP_TRY(hipMemcpyAsync(c->h_flags, flags, kFlagWords * 4, hipMemcpyDeviceToHost, s));
                 HIP_TRY(hipStreamSynchronize(s));
-                if (c->h_flags[kChunk - 1] == 0) break;
+                uint32_t any = 0;
+                for (uint32_t k = 0; k < kFlagWords; k += 32) any |= c->h_flags[k];
+                if (!any) break;
             }
             launch_accumulate(s, c->accum.as<float>(), npix, c->rad.as<float>(), rad_plane, nb, s0 == 0);
         }
@@ -321,6 +359,7 @@ int render_impl(rrt_ctx *c, const rrt_render_params *pp, void *d_rgb8, void *d_a
         st.rays = h[ST_RAYS]; st.inner_visits = h[ST_INNER]; st.leaf_tests = h[ST_LEAF];
         st.hits_lambertian = h[ST_HL]; st.hits_metal = h[ST_HM]; st.hits_dielectric = h[ST_HD];
         st.sky_misses = h[ST_SKY]; st.paths = h[ST_PATHS]; st.depth_cut = h[ST_DEPTHCUT]; st.absorbed = h[ST_ABSORBED];
+        for (int k = 0; k < 6; k++) st.debug[k] = h[10 + k];
     }
     double ext = 0.0;
     for (size_t i = 0; i + 1 < kev_used; i += 2) {

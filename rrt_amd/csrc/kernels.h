@@ -28,7 +28,8 @@ struct SceneDev {
     const float4 *motion;     // {centre1 - centre0, time0}
     const float *motion_dt;   // time1 - time0
     const uint32_t *sph_info;
-    const float4 *mat;        // {albedo, fuzz | ref_idx}
+    const float4 *mat;        // {albedo, fuzz | ref_idx} per material
+    const float4 *pmat;       // the same, per sphere: one gather less in shade
     const float4 *prim_att;   // attenuation per sphere
     uint32_t flags;
     float u_time0, u_dt;
@@ -44,13 +45,17 @@ struct SceneDev {
 struct PathState {
     float4 *rayA;      // origin xyz, time
     float4 *rayB;      // direction xyz, path id within the batch (as bits)
+    float4 *rayC;      // 1/direction xyz (types.rs:21-23), direction.direction (sphere.rs:71): per-ray constants of the walk
     uint4 *rng;        // Xoshiro128Plus state
-    uint32_t *depth;   // scatters so far
+    uint32_t *depth;   // scatters so far (low 16 bits) | trail entries written (high 16 bits)
     uint2 *hit;        // extend -> shade: {t bits, sphere index or kPrimNone}
-    uint32_t *trail;   // [depth][slot] sphere hit at each scatter, for the back-to-front product
+    uint4 *recent;     // the four newest spheres the path scattered off (dielectrics excepted), newest first
+    uint32_t *trail;   // [slot / 64][level][slot % 64] the older ones; both feed the back-to-front product of lib.rs:62
     uint32_t *queue;
     uint32_t *qcount;
     uint32_t n_slots;  // multiple of kWaveSlots
+    uint32_t trail_levels;  // levels per path in `trail` (the depth limit)
+    uint32_t wave_begin, wave_end;  // the waves (slot stretches) one launch works on
 };
 
 struct BatchDev {
@@ -65,11 +70,12 @@ struct BatchDev {
     uint32_t max_depth;
     uint32_t *cursors;         // n_shards counters, kCursorStride words apart
     uint32_t n_shards;         // min(kCursorShards, waves): every shard must be served by at least one wave
-    uint32_t *alive_flag;      // set to 1 by any wave that still owns live paths after shading
+    uint32_t *alive_flag;      // null, or 32 words 128 bytes apart: a wave that still owns live paths after shading sets one
 };
 
 void launch_raygen(hipStream_t s, const PathState &P, const BatchDev &B, const CameraDev &C, uint64_t *wave_stats);
-void launch_extend(hipStream_t s, const SceneDev &S, const PathState &P, bool moving, bool count, uint64_t *wave_stats);
+void launch_extend(hipStream_t s, const SceneDev &S, const PathState &P, bool moving, bool count, uint32_t retire_min,
+                   uint32_t leaf_min, uint64_t *wave_stats);
 void launch_shade(hipStream_t s, const SceneDev &S, const PathState &P, const BatchDev &B, const CameraDev &C, bool moving,
                   bool count, uint64_t *wave_stats);
 // accum[3][npix] += rad planes, sample by sample in order (lib.rs:96-103)

@@ -21,6 +21,8 @@ DEV float u2f(uint32_t u) { return __uint_as_float(u); }
 DEV uint32_t f2u(float f) { return __float_as_uint(f); }
 DEV uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));  // one v_pk_* operand
+
 struct V3 { float x, y, z; };
 DEV V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
 DEV V3 add(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -78,8 +80,11 @@ DEV V3 in_unit_sphere(Rng &g) {  // rng.rs:32-40
     }
 }
 
+// Per-ray constants of the walk, computed once where the ray is made: 1/d (types.rs:21-23) and d.d (sphere.rs:71)
+DEV float4 ray_constants(V3 d) { return make_float4(1.0f / d.x, 1.0f / d.y, 1.0f / d.z, dot3(d, d)); }
+
 // ---- path generation (lib.rs:93-101, camera.rs:56-66) ----
-DEV void generate_path(const BatchDev &Bt, const CameraDev &C, uint32_t p, float4 &A, float4 &B, Rng &g) {
+DEV void generate_path(const BatchDev &Bt, const CameraDev &C, uint32_t p, float4 &A, float4 &B, float4 &K, Rng &g) {
     const uint32_t sl = p / Bt.npix;
     const uint32_t pl = p - sl * Bt.npix;
     const uint32_t idx = Bt.pixel_map ? Bt.pixel_map[pl] : pl;
@@ -104,73 +109,157 @@ DEV void generate_path(const BatchDev &Bt, const CameraDev &C, uint32_t p, float
     const float time = tv * C.time_scale + C.time_low;  // rand Uniform::sample (camera.rs:64)
     A = make_float4(origin.x, origin.y, origin.z, time);
     B = make_float4(dir.x, dir.y, dir.z, u2f(p));
+    K = ray_constants(dir);
 }
 
-// ---- BVH traversal (acceleration.rs:221-272) over the linked layout of scene_layout.h ----
-template <bool MOVING, bool COUNT>
-DEV void traverse(const SceneDev &S, V3 o, V3 d, float time, float tmin, float &tmax, uint32_t &best, uint32_t &n_inner,
-                  uint32_t &n_leaf) {
-    const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // types.rs:21-23
-    const bool ngx = inv.x < 0.0f, ngy = inv.y < 0.0f, ngz = inv.z < 0.0f;  // acceleration.rs:230
-    const uint32_t oct = (ngx ? 1u : 0u) | (ngy ? 2u : 0u) | (ngz ? 4u : 0u);
-    const float a = dot3(d, d);  // sphere.rs:71, the same for every sphere
-    float f_ray = 0.0f;
-    if (MOVING && (S.flags & kSceneUniformTimes)) f_ray = (time - S.u_time0) / S.u_dt;
-    const uint32_t *nw = reinterpret_cast<const uint32_t *>(S.nodes);
-    uint32_t cur = S.root_ref;
-    while (cur != kRefEnd) {
+// ---- BVH traversal (acceleration.rs:221-272) over the linked layouts of scene_layout.h ----
+//
+// A node store hands out the words of a node; two exist: the 64-byte nodes in HBM (any scene) and the compact copy in
+// LDS (small scenes).  References order as inner < kEnd < leaf, so `cur < kEnd` means "inner node".
+struct RayCtx {
+    V3 o, d, inv;
+    float a;      // d.d (sphere.rs:71), the same for every sphere
+    float time, f_ray;
+    float tmin, tmax;
+    uint32_t oct;   // bit k set: 1/d[k] < 0 (acceleration.rs:230-231)
+    uint32_t best;  // store-specific handle of the closest leaf so far
+};
+
+DEV void ray_load(RayCtx &r, float4 A, float4 B, float4 C, float tmin, float tmax, const SceneDev &S, bool uniform_times) {
+    r.o = mk(A.x, A.y, A.z);
+    r.d = mk(B.x, B.y, B.z);
+    r.time = A.w;
+    r.inv = mk(C.x, C.y, C.z);
+    r.oct = (r.inv.x < 0.0f ? 1u : 0u) | (r.inv.y < 0.0f ? 2u : 0u) | (r.inv.z < 0.0f ? 4u : 0u);  // acceleration.rs:230-231
+    r.a = C.w;
+    r.f_ray = uniform_times ? (r.time - S.u_time0) / S.u_dt : 0.0f;
+    r.tmin = tmin;
+    r.tmax = tmax;
+    r.best = kPrimNone;
+}
+
+DEV void ray_setup(RayCtx &r, float4 A, float4 B, float tmin, float tmax, const SceneDev &S, bool uniform_times) {
+    r.o = mk(A.x, A.y, A.z);
+    r.d = mk(B.x, B.y, B.z);
+    r.time = A.w;
+    r.inv = mk(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);  // types.rs:21-23
+    r.oct = (r.inv.x < 0.0f ? 1u : 0u) | (r.inv.y < 0.0f ? 2u : 0u) | (r.inv.z < 0.0f ? 4u : 0u);
+    r.a = dot3(r.d, r.d);
+    r.f_ray = uniform_times ? (r.time - S.u_time0) / S.u_dt : 0.0f;  // center_at's factor when every moving sphere shares its shutter interval
+    r.tmin = tmin;
+    r.tmax = tmax;
+    r.best = kPrimNone;
+}
+
+template <bool MOVING>
+struct HbmStore {
+    static constexpr uint32_t kEnd = kRefEnd;
+    const SceneDev &S;
+    DEV explicit HbmStore(const SceneDev &s) : S(s) {}
+    DEV uint32_t root() const { return S.root_ref; }
+    DEV bool uniform_times() const { return MOVING && (S.flags & kSceneUniformTimes); }
+    DEV void inner(uint32_t cur, uint32_t oct, f32x2 &bx, f32x2 &by, f32x2 &bz, uint32_t &near_ref, uint32_t &exit_ref) const {
         const uint32_t idx = cur & kRefIndexMask;
         const uint4 n0 = S.nodes[idx * 4u];
         const uint4 n1 = S.nodes[idx * 4u + 1u];
-        const uint32_t exit_ref = nw[idx * kNodeWords + 8u + oct];
-        if (cur & kRefLeafBit) {
-            // Sphere::hit (sphere.rs:68-85); the Hit record itself is rebuilt in shade for the final hit only
-            if (COUNT) n_leaf++;
-            V3 c = mk(u2f(n0.x), u2f(n0.y), u2f(n0.z));
-            const float rr = u2f(n0.w);
-            const uint32_t prim = n1.x;
-            if (MOVING && (n1.y & 1u)) {  // center_at (sphere.rs:61-64)
-                const float4 m = S.motion[prim];
-                const float f = (S.flags & kSceneUniformTimes) ? f_ray : (time - m.w) / S.motion_dt[prim];
-                c = add(c, scale(f, mk(m.x, m.y, m.z)));
-            }
-            const V3 oc = sub(o, c);
-            const float half_b = dot3(oc, d);
-            const float cc = dot3(oc, oc) - rr;
-            const float disc = (half_b * half_b) - (a * cc);
-            if (!(disc < 0.0f)) {
-                const float sq = sqrtf(disc);
-                float root = (-half_b - sq) / a;
-                bool outside = root < tmin || tmax < root;
-                if (outside) {
-                    root = (-half_b + sq) / a;
-                    outside = root < tmin || tmax < root;
-                }
-                if (!outside) { tmax = root; best = prim; }
-            }
-            cur = exit_ref;
-        } else {
-            // Aabb::intersect (acceleration.rs:60-84) against the current t_max
-            if (COUNT) n_inner++;
-            const float lox = u2f(n0.x), loy = u2f(n0.y), loz = u2f(n0.z), hix = u2f(n0.w), hiy = u2f(n1.x), hiz = u2f(n1.y);
-            const float tnx = ((ngx ? hix : lox) - o.x) * inv.x;
-            const float tny = ((ngy ? hiy : loy) - o.y) * inv.y;
-            const float tnz = ((ngz ? hiz : loz) - o.z) * inv.z;
-            const float tfx = (((ngx ? lox : hix) - o.x) * inv.x) * RRT_FAR_SCALE;
-            const float tfy = (((ngy ? loy : hiy) - o.y) * inv.y) * RRT_FAR_SCALE;
-            const float tfz = (((ngz ? loz : hiz) - o.z) * inv.z) * RRT_FAR_SCALE;
-            const float t0 = fmaxf(fmaxf(fmaxf(tnx, tny), tnz), tmin);
-            const float t1 = fminf(fminf(fminf(tfx, tfy), tfz), tmax);
-            if (t0 <= t1) {
-                // children are visited near side first (acceleration.rs:253-267); the far one is the near one's exit
-                const uint32_t axis = (n1.z >> RRT_NODE_AXIS_SHIFT) & 3u;
-                const bool neg_axis = (oct >> axis) & 1u;
-                cur = neg_axis ? (n1.z & (kRefLeafBit | kRefIndexMask)) : n1.w;
-            } else {
-                cur = exit_ref;
-            }
+        exit_ref = reinterpret_cast<const uint32_t *>(S.nodes)[idx * kNodeWords + 8u + oct];
+        bx = f32x2{u2f(n0.x), u2f(n0.y)}; by = f32x2{u2f(n0.z), u2f(n0.w)}; bz = f32x2{u2f(n1.x), u2f(n1.y)};
+        const uint32_t axis = (n1.z >> RRT_NODE_AXIS_SHIFT) & 3u;
+        near_ref = ((oct >> axis) & 1u) ? (n1.z & (kRefLeafBit | kRefIndexMask)) : n1.w;  // acceleration.rs:253-267
+    }
+    DEV void leaf(uint32_t cur, const RayCtx &r, V3 &c, float &rr, uint32_t &handle, uint32_t &exit_ref) const {
+        const uint32_t idx = cur & kRefIndexMask;
+        const uint4 n0 = S.nodes[idx * 4u];
+        const uint4 n1 = S.nodes[idx * 4u + 1u];
+        exit_ref = reinterpret_cast<const uint32_t *>(S.nodes)[idx * kNodeWords + 8u + r.oct];
+        c = mk(u2f(n0.x), u2f(n0.y), u2f(n0.z));
+        rr = u2f(n0.w);
+        handle = n1.x;
+        if (MOVING && (n1.y & 1u)) {  // center_at (sphere.rs:61-64)
+            const float4 m = S.motion[n1.x];
+            const float f = (S.flags & kSceneUniformTimes) ? r.f_ray : (r.time - m.w) / S.motion_dt[n1.x];
+            c = add(c, scale(f, mk(m.x, m.y, m.z)));
         }
     }
+    DEV uint32_t prim_of(uint32_t handle) const { return handle; }
+};
+
+template <bool MOVING>
+struct LdsStore {
+    static constexpr uint32_t kEnd = kRef16End;
+    static constexpr uint32_t W = MOVING ? kSmallWordsMoving : kSmallWordsStatic;
+    const uint4 *v4;
+    uint32_t root16;
+    DEV LdsStore(const uint4 *p, uint32_t r) : v4(p), root16(r) {}
+    DEV uint32_t root() const { return root16; }
+    DEV bool uniform_times() const { return MOVING; }  // the compact copy exists only for scenes with one shutter interval
+    DEV void inner(uint32_t cur, uint32_t oct, f32x2 &bx, f32x2 &by, f32x2 &bz, uint32_t &near_ref, uint32_t &exit_ref) const {
+        const uint32_t off = __umul24(cur, W / 4u);  // cur is an inner-node index here, far below 2^24
+        const uint4 n0 = v4[off];
+        const uint4 n1 = v4[off + 1u];
+        exit_ref = reinterpret_cast<const uint16_t *>(v4)[off * 8u + 16u + oct];
+        bx = f32x2{u2f(n0.x), u2f(n0.y)}; by = f32x2{u2f(n0.z), u2f(n0.w)}; bz = f32x2{u2f(n1.x), u2f(n1.y)};
+        near_ref = ((oct >> n1.w) & 1u) ? (n1.z >> 16) : (n1.z & 0xFFFFu);
+    }
+    DEV void leaf(uint32_t cur, const RayCtx &r, V3 &c, float &rr, uint32_t &handle, uint32_t &exit_ref) const {
+        const uint32_t idx = cur & (kRef16LeafBit - 1u);
+        const uint4 n0 = v4[idx * (W / 4u)];
+        exit_ref = reinterpret_cast<const uint16_t *>(v4)[idx * (W * 2u) + 16u + r.oct];
+        c = mk(u2f(n0.x), u2f(n0.y), u2f(n0.z));
+        rr = u2f(n0.w);
+        handle = idx;
+        if (MOVING) {
+            const uint4 m = v4[idx * (W / 4u) + 3u];  // centre1 - centre0, zero words for a sphere at rest
+            if (reinterpret_cast<const uint32_t *>(v4)[idx * W + 5u] & 1u) c = add(c, scale(r.f_ray, mk(u2f(m.x), u2f(m.y), u2f(m.z))));
+        }
+    }
+    DEV uint32_t prim_of(uint32_t handle) const { return reinterpret_cast<const uint32_t *>(v4)[handle * W + 4u]; }
+};
+
+// Aabb::intersect (acceleration.rs:60-84) against the current t_max, then the step of acceleration.rs:250-267.
+// Node boxes are stored as (min, max) pairs per axis, so both planes of an axis go through one packed subtract and
+// one packed multiply; which of the two results is "near" is chosen afterwards by the sign of 1/d, which selects
+// the same operands the reference's blend selects before its arithmetic.
+template <class Store>
+DEV uint32_t visit_inner(const Store &st, uint32_t cur, const RayCtx &r) {
+    f32x2 bx, by, bz;
+    uint32_t near_ref, exit_ref;
+    st.inner(cur, r.oct, bx, by, bz, near_ref, exit_ref);
+    const f32x2 tx = (bx - f32x2{r.o.x, r.o.x}) * f32x2{r.inv.x, r.inv.x};
+    const f32x2 ty = (by - f32x2{r.o.y, r.o.y}) * f32x2{r.inv.y, r.inv.y};
+    const f32x2 tz = (bz - f32x2{r.o.z, r.o.z}) * f32x2{r.inv.z, r.inv.z};
+    const bool ngx = r.oct & 1u, ngy = r.oct & 2u, ngz = r.oct & 4u;
+    const float tnx = ngx ? tx.y : tx.x, tny = ngy ? ty.y : ty.x, tnz = ngz ? tz.y : tz.x;
+    const float tfx = (ngx ? tx.x : tx.y) * RRT_FAR_SCALE;
+    const float tfy = (ngy ? ty.x : ty.y) * RRT_FAR_SCALE;
+    const float tfz = (ngz ? tz.x : tz.y) * RRT_FAR_SCALE;
+    const float t0 = fmaxf(fmaxf(fmaxf(tnx, tny), tnz), r.tmin);
+    const float t1 = fminf(fminf(fminf(tfx, tfy), tfz), r.tmax);
+    return (t0 <= t1) ? near_ref : exit_ref;  // the far child is the near child's exit link
+}
+
+// Sphere::hit (sphere.rs:68-85); the Hit record itself is rebuilt in shade, for the final hit only
+template <class Store>
+DEV uint32_t visit_leaf(const Store &st, uint32_t cur, RayCtx &r) {
+    V3 c;
+    float rr;
+    uint32_t handle, exit_ref;
+    st.leaf(cur, r, c, rr, handle, exit_ref);
+    const V3 oc = sub(r.o, c);
+    const float half_b = dot3(oc, r.d);
+    const float cc = dot3(oc, oc) - rr;
+    const float disc = (half_b * half_b) - (r.a * cc);
+    if (!(disc < 0.0f)) {
+        const float sq = sqrtf(disc);
+        float root = (-half_b - sq) / r.a;
+        bool outside = root < r.tmin || r.tmax < root;
+        if (outside) {
+            root = (-half_b + sq) / r.a;
+            outside = root < r.tmin || r.tmax < root;
+        }
+        if (!outside) { r.tmax = root; r.best = handle; }
+    }
+    return exit_ref;
 }
 
 DEV uint64_t wave_sum_u64(uint64_t v) {
@@ -178,131 +267,124 @@ DEV uint64_t wave_sum_u64(uint64_t v) {
     return v;
 }
 
-template <bool MOVING, bool COUNT>
-__global__ __launch_bounds__(kBlockThreads) void k_extend(SceneDev S, PathState P, uint64_t *wave_stats) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = (blockIdx.x * kBlockThreads + threadIdx.x) >> 6;
+// One wave's share of an extend launch.  The wave's live-slot list is a pool of rays: whenever lanes finish their ray
+// they are given the next rays of the list, which a look-ahead buffer has already brought in from HBM.  Inside a ray the walk alternates "descend through inner nodes" and "test one
+// sphere" (the latter once `leaf_min` lanes wait for it), so that lanes run the same kind of step together.  Finished
+// lanes wait until at least `retire_min` of them can be retired and restarted in one go (or nothing else is left).
+template <class Store, bool MOVING, bool COUNT>
+DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uint32_t wave, uint32_t lane, uint32_t retire_min,
+                     uint32_t leaf_min, uint64_t *wave_stats) {
     const uint32_t base = wave * kWaveSlots;
-    if (base >= P.n_slots) return;
     const uint32_t count = rfl(P.qcount[wave]);
     if (count == 0) return;
+    const bool uniform_times = st.uniform_times();
     uint32_t n_inner = 0, n_leaf = 0;
-    for (uint32_t i = lane; i < count; i += 64u) {
-        const uint32_t slot = P.queue[base + i];
-        const float4 A = P.rayA[slot];
-        const float4 B = P.rayB[slot];
-        float tmax = __FLT_MAX__;
-        uint32_t best = kPrimNone;
-        traverse<MOVING, COUNT>(S, mk(A.x, A.y, A.z), mk(B.x, B.y, B.z), A.w, 0.001f, tmax, best, n_inner, n_leaf);  // lib.rs:57
-        P.hit[slot] = make_uint2(f2u(tmax), best);
-    }
-    uint64_t *st = wave_stats + (size_t)wave * kWaveStatWords;
-    if (COUNT) {
-        const uint64_t si = wave_sum_u64(n_inner), sl = wave_sum_u64(n_leaf);
-        if (lane == 0) { st[ST_INNER] += si; st[ST_LEAF] += sl; }
-    }
-    if (lane == 0) st[ST_RAYS] += count;
-}
-
-// The same walk over the compact node copy held in LDS (16-bit references, scene_layout.h).  `best` receives the
-// node index of the closest leaf; the caller turns it into a sphere index with one more LDS read.
-template <bool MOVING, bool COUNT>
-DEV void traverse_lds(const uint4 *lds4, uint32_t root16, const SceneDev &S, V3 o, V3 d, float time, float tmin, float &tmax,
-                      uint32_t &best_node, uint32_t &n_inner, uint32_t &n_leaf) {
-    constexpr uint32_t W = MOVING ? kSmallWordsMoving : kSmallWordsStatic;
-    const uint16_t *lds16 = reinterpret_cast<const uint16_t *>(lds4);
-    const uint32_t *lds32 = reinterpret_cast<const uint32_t *>(lds4);
-    const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    const bool ngx = inv.x < 0.0f, ngy = inv.y < 0.0f, ngz = inv.z < 0.0f;
-    const uint32_t oct = (ngx ? 1u : 0u) | (ngy ? 2u : 0u) | (ngz ? 4u : 0u);
-    const float a = dot3(d, d);
-    float f_ray = 0.0f;
-    if (MOVING) f_ray = (time - S.u_time0) / S.u_dt;  // the compact copy exists only when all moving spheres share their shutter interval
-    uint32_t cur = root16;
-    while (cur != kRef16End) {
-        const uint32_t idx = cur & (kRef16LeafBit - 1u);
-        const uint4 n0 = lds4[idx * (W / 4u)];
-        if (cur & kRef16LeafBit) {
+    uint32_t d_desc_iters = 0, d_desc_lanes = 0, d_leaf_iters = 0, d_leaf_lanes = 0, d_retires = 0, d_retire_lanes = 0;  // COUNT only
+    // the lane's column of the live-slot list, read up front so that no ray load ever waits for a list load
+    static_assert(kWaveSlots == 256, "four list entries per lane");
+    const uint32_t q0 = lane < count ? P.queue[base + lane] : 0u;
+    const uint32_t q1 = lane + 64u < count ? P.queue[base + lane + 64u] : 0u;
+    const uint32_t q2 = lane + 128u < count ? P.queue[base + lane + 128u] : 0u;
+    const uint32_t q3 = lane + 192u < count ? P.queue[base + lane + 192u] : 0u;
+    // Look-ahead buffer: lane l always holds the not yet started ray of list position l + 64*bj (its own column, so
+    // the loads need no address from another load).  Rays are handed out in list order to whichever lanes retire, by
+    // a cross-lane read of the buffer; a consumed buffer entry is refilled at once and arrives while the walk goes on.
+    uint32_t bj = 0, bslot = q0, slot = 0;
+    bool bvalid = lane < count, has = false;
+    float4 bA = make_float4(0, 0, 0, 0), bB = bA, bC = bA;
+    if (bvalid) { bA = P.rayA[bslot]; bB = P.rayB[bslot]; bC = P.rayC[bslot]; }
+    uint32_t head = 0;  // first list position not handed out yet (wave-uniform)
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    RayCtx r;
+    ray_load(r, bA, bB, bC, 0.001f, __FLT_MAX__, S, false);
+    uint32_t cur = Store::kEnd;
+    for (;;) {
+        const bool idle = cur == Store::kEnd;
+        const uint64_t idle_m = __ballot(idle);
+        const uint64_t ready = __ballot(idle && (has || head < count));
+        if (~idle_m == 0ull || (uint32_t)__popcll(ready) >= retire_min) {
+            if (COUNT) { d_retires++; d_retire_lanes += (uint32_t)__popcll(ready); }
+            if (idle && has) {
+                P.hit[slot] = make_uint2(f2u(r.tmax), r.best == kPrimNone ? kPrimNone : st.prim_of(r.best));
+                has = false;
+            }
+            // every idle lane takes the next ray of the list, in lane order
+            const uint32_t pos = head + (uint32_t)__popcll(idle_m & lt_mask);
+            const int src = (int)(pos & 63u);
+            const uint32_t n_slot = (uint32_t)__shfl((int)bslot, src, 64);
+            float4 nA, nB, nC;
+            nA.x = __shfl(bA.x, src, 64); nA.y = __shfl(bA.y, src, 64); nA.z = __shfl(bA.z, src, 64); nA.w = __shfl(bA.w, src, 64);
+            nB.x = __shfl(bB.x, src, 64); nB.y = __shfl(bB.y, src, 64); nB.z = __shfl(bB.z, src, 64); nB.w = __shfl(bB.w, src, 64);
+            nC.x = __shfl(bC.x, src, 64); nC.y = __shfl(bC.y, src, 64); nC.z = __shfl(bC.z, src, 64); nC.w = __shfl(bC.w, src, 64);
+            if (idle && pos < count) {
+                slot = n_slot;
+                ray_load(r, nA, nB, nC, 0.001f, __FLT_MAX__, S, uniform_times);  // lib.rs:57
+                cur = st.root();
+                has = true;
+            }
+            const uint32_t taken = min((uint32_t)__popcll(idle_m), count - head);
+            if (bvalid && ((lane - head) & 63u) < taken) {  // this lane's buffer entry was handed out: fetch the column's next
+                bj++;
+                bslot = bj == 1u ? q1 : (bj == 2u ? q2 : q3);
+                bvalid = bj < 4u && lane + 64u * bj < count;
+                if (bvalid) { bA = P.rayA[bslot]; bB = P.rayB[bslot]; bC = P.rayC[bslot]; }
+            }
+            head += taken;
+            if (__ballot(has) == 0ull) break;
+        }
+        // descend until no lane is at an inner node, or enough lanes wait at a sphere for a test to be worth a pass
+        for (;;) {
+            const bool at_inner = cur < Store::kEnd;
+            const uint64_t im = __ballot(at_inner);
+            if (im == 0ull) break;
+            if (COUNT) { d_desc_iters++; d_desc_lanes += (uint32_t)__popcll(im); }
+            if (at_inner) {
+                if (COUNT) n_inner++;
+                cur = visit_inner(st, cur, r);
+            }
+            if ((uint32_t)__popcll(__ballot(cur > Store::kEnd)) >= leaf_min) break;
+        }
+        if (COUNT) { const uint64_t lm = __ballot(cur > Store::kEnd); if (lm) { d_leaf_iters++; d_leaf_lanes += (uint32_t)__popcll(lm); } }
+        if (cur > Store::kEnd) {
             if (COUNT) n_leaf++;
-            V3 c = mk(u2f(n0.x), u2f(n0.y), u2f(n0.z));
-            const float rr = u2f(n0.w);
-            if (MOVING) {
-                if (lds32[idx * W + 5u] & 1u) {
-                    const uint4 m = lds4[idx * (W / 4u) + 3u];
-                    c = add(c, scale(f_ray, mk(u2f(m.x), u2f(m.y), u2f(m.z))));
-                }
-            }
-            const V3 oc = sub(o, c);
-            const float half_b = dot3(oc, d);
-            const float cc = dot3(oc, oc) - rr;
-            const float disc = (half_b * half_b) - (a * cc);
-            if (!(disc < 0.0f)) {
-                const float sq = sqrtf(disc);
-                float root = (-half_b - sq) / a;
-                bool outside = root < tmin || tmax < root;
-                if (outside) {
-                    root = (-half_b + sq) / a;
-                    outside = root < tmin || tmax < root;
-                }
-                if (!outside) { tmax = root; best_node = idx; }
-            }
-            cur = lds16[idx * (W * 2u) + 16u + oct];
-        } else {
-            if (COUNT) n_inner++;
-            const uint4 n1 = lds4[idx * (W / 4u) + 1u];
-            const float lox = u2f(n0.x), loy = u2f(n0.y), loz = u2f(n0.z), hix = u2f(n0.w), hiy = u2f(n1.x), hiz = u2f(n1.y);
-            const float tnx = ((ngx ? hix : lox) - o.x) * inv.x;
-            const float tny = ((ngy ? hiy : loy) - o.y) * inv.y;
-            const float tnz = ((ngz ? hiz : loz) - o.z) * inv.z;
-            const float tfx = (((ngx ? lox : hix) - o.x) * inv.x) * RRT_FAR_SCALE;
-            const float tfy = (((ngy ? loy : hiy) - o.y) * inv.y) * RRT_FAR_SCALE;
-            const float tfz = (((ngz ? loz : hiz) - o.z) * inv.z) * RRT_FAR_SCALE;
-            const float t0 = fmaxf(fmaxf(fmaxf(tnx, tny), tnz), tmin);
-            const float t1 = fminf(fminf(fminf(tfx, tfy), tfz), tmax);
-            if (t0 <= t1) {
-                const bool neg_axis = (oct >> n1.w) & 1u;
-                cur = neg_axis ? (n1.z >> 16) : (n1.z & 0xFFFFu);
-            } else {
-                cur = lds16[idx * (W * 2u) + 16u + oct];
-            }
+            cur = visit_leaf(st, cur, r);
         }
     }
+    uint64_t *stt = wave_stats + (size_t)wave * kWaveStatWords;
+    if (COUNT) {
+        const uint64_t si = wave_sum_u64(n_inner), sl = wave_sum_u64(n_leaf);
+        if (lane == 0) {
+            stt[ST_INNER] += si; stt[ST_LEAF] += sl;
+            stt[10] += d_desc_iters; stt[11] += d_desc_lanes; stt[12] += d_leaf_iters; stt[13] += d_leaf_lanes; stt[14] += d_retires;
+            stt[15] += d_retire_lanes;
+        }
+    }
+    if (lane == 0) stt[ST_RAYS] += count;
+}
+
+template <bool MOVING, bool COUNT>
+__global__ __launch_bounds__(kBlockThreads) void k_extend(SceneDev S, PathState P, uint32_t retire_min, uint32_t leaf_min, uint64_t *wave_stats) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = P.wave_begin + ((blockIdx.x * kBlockThreads + threadIdx.x) >> 6);
+    if (wave >= P.wave_end) return;
+    const HbmStore<MOVING> st(S);
+    extend_wave<HbmStore<MOVING>, MOVING, COUNT>(st, S, P, wave, lane, retire_min, leaf_min, wave_stats);
 }
 
 constexpr uint32_t kLdsBlockThreads = 1024;  // 16 waves share one LDS copy of the scene
 
 template <bool MOVING, bool COUNT>
-__global__ __launch_bounds__(kLdsBlockThreads) void k_extend_lds(SceneDev S, PathState P, uint64_t *wave_stats) {
+__global__ __launch_bounds__(kLdsBlockThreads, 8) void k_extend_lds(SceneDev S, PathState P, uint32_t retire_min, uint32_t leaf_min,
+                                                                  uint64_t *wave_stats) {
     extern __shared__ uint4 lds4[];
-    constexpr uint32_t W = MOVING ? kSmallWordsMoving : kSmallWordsStatic;
-    const uint32_t n_vec = S.n_nodes * (W / 4u);
+    const uint32_t n_vec = S.n_nodes * (LdsStore<MOVING>::W / 4u);
     for (uint32_t i = threadIdx.x; i < n_vec; i += kLdsBlockThreads) lds4[i] = S.small_nodes[i];
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = (blockIdx.x * kLdsBlockThreads + threadIdx.x) >> 6;
-    const uint32_t base = wave * kWaveSlots;
-    if (base >= P.n_slots) return;
-    const uint32_t count = rfl(P.qcount[wave]);
-    if (count == 0) return;
-    const uint32_t *lds32 = reinterpret_cast<const uint32_t *>(lds4);
-    uint32_t n_inner = 0, n_leaf = 0;
-    for (uint32_t i = lane; i < count; i += 64u) {
-        const uint32_t slot = P.queue[base + i];
-        const float4 A = P.rayA[slot];
-        const float4 B = P.rayB[slot];
-        float tmax = __FLT_MAX__;
-        uint32_t best_node = kPrimNone;
-        traverse_lds<MOVING, COUNT>(lds4, S.small_root, S, mk(A.x, A.y, A.z), mk(B.x, B.y, B.z), A.w, 0.001f, tmax, best_node, n_inner,
-                                    n_leaf);
-        const uint32_t best = best_node == kPrimNone ? kPrimNone : lds32[best_node * W + 4u];
-        P.hit[slot] = make_uint2(f2u(tmax), best);
-    }
-    uint64_t *st = wave_stats + (size_t)wave * kWaveStatWords;
-    if (COUNT) {
-        const uint64_t si = wave_sum_u64(n_inner), sl = wave_sum_u64(n_leaf);
-        if (lane == 0) { st[ST_INNER] += si; st[ST_LEAF] += sl; }
-    }
-    if (lane == 0) st[ST_RAYS] += count;
+    const uint32_t wave = P.wave_begin + ((blockIdx.x * kLdsBlockThreads + threadIdx.x) >> 6);
+    if (wave >= P.wave_end) return;
+    const LdsStore<MOVING> st(lds4, S.small_root);
+    extend_wave<LdsStore<MOVING>, MOVING, COUNT>(st, S, P, wave, lane, retire_min, leaf_min, wave_stats);
 }
 
 // (1 - cos)^5 of materials.rs:68, as a double-precision product rounded once to f32
@@ -313,194 +395,279 @@ DEV float reflectance(float cosine, float ref_idx) {  // materials.rs:65-69
     return r0 + (1.0f - r0) * pow5(1.0f - cosine);
 }
 
-// Claims path ids for the lanes in `need` from this wave's cursor shard and starts those paths.
-// Path ids are dealt in groups of 64 consecutive ids, group g belonging to shard g % n_shards.
-DEV void regenerate(const PathState &P, const BatchDev &Bt, const CameraDev &C, uint32_t lane, uint32_t shard, bool need,
-                    uint32_t slot, bool &alive, uint32_t &n_started) {
-    const uint64_t nm = __ballot(need);
-    if (nm == 0ull) return;
-    const uint32_t cnt = (uint32_t)__popcll(nm);
-    const uint32_t leader = (uint32_t)__ffsll((long long)nm) - 1u;
+// Path ids are dealt in groups of 64 consecutive ids, group g belonging to cursor shard g % n_shards; a wave draws
+// from shard wave % n_shards.  `n` is the wave's running count of claims from its shard.
+DEV bool start_path(const PathState &P, const BatchDev &Bt, const CameraDev &C, uint32_t shard, uint32_t n, uint32_t slot) {
+    const uint64_t p64 = ((uint64_t)(n >> 6) * Bt.n_shards + shard) * 64ull + (n & 63u);
+    if (p64 >= (uint64_t)Bt.n_paths) return false;
+    float4 A, B, K;
+    Rng g;
+    generate_path(Bt, C, (uint32_t)p64, A, B, K, g);
+    P.rayA[slot] = A;
+    P.rayB[slot] = B;
+    P.rayC[slot] = K;
+    P.rng[slot] = make_uint4(g.s0, g.s1, g.s2, g.s3);
+    P.depth[slot] = 0u;
+    return true;
+}
+
+// One claim of `cnt` path ids from the shard's cursor by lane 0, broadcast to the wave
+DEV uint32_t claim_paths(const BatchDev &Bt, uint32_t lane, uint32_t shard, uint32_t cnt) {
     uint32_t base_n = 0;
-    if (lane == leader) base_n = atomicAdd(&Bt.cursors[shard * kCursorStride], cnt);
-    base_n = __shfl(base_n, (int)leader, 64);
-    bool started = false;
-    if (need) {
-        const uint32_t n = base_n + (uint32_t)__popcll(nm & ((1ull << lane) - 1ull));
-        const uint64_t p64 = ((uint64_t)(n >> 6) * Bt.n_shards + shard) * 64ull + (n & 63u);
-        if (p64 < (uint64_t)Bt.n_paths) {
-            float4 A, B;
-            Rng g;
-            generate_path(Bt, C, (uint32_t)p64, A, B, g);
-            P.rayA[slot] = A;
-            P.rayB[slot] = B;
-            P.rng[slot] = make_uint4(g.s0, g.s1, g.s2, g.s3);
-            P.depth[slot] = 0u;
-            alive = true;
-            started = true;
-        }
-    }
-    n_started += (uint32_t)__popcll(__ballot(started));
+    if (lane == 0 && cnt) base_n = atomicAdd(&Bt.cursors[shard * kCursorStride], cnt);
+    return (uint32_t)__shfl((int)base_n, 0, 64);
 }
 
 __global__ __launch_bounds__(kBlockThreads) void k_raygen(PathState P, BatchDev Bt, CameraDev C, uint64_t *wave_stats) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = (blockIdx.x * kBlockThreads + threadIdx.x) >> 6;
+    const uint32_t wave = P.wave_begin + ((blockIdx.x * kBlockThreads + threadIdx.x) >> 6);
     const uint32_t base = wave * kWaveSlots;
-    if (base >= P.n_slots) return;
+    if (wave >= P.wave_end) return;
     const uint32_t shard = wave % Bt.n_shards;
-    uint32_t out_count = 0, n_started = 0;
+    const uint32_t base_n = claim_paths(Bt, lane, shard, kWaveSlots);
+    uint32_t out_count = 0;
     for (uint32_t t0 = 0; t0 < kWaveSlots; t0 += 64u) {
         const uint32_t slot = base + t0 + lane;
-        bool alive = false;
-        regenerate(P, Bt, C, lane, shard, true, slot, alive, n_started);
+        const bool alive = start_path(P, Bt, C, shard, base_n + t0 + lane, slot);
         const uint64_t am = __ballot(alive);
         if (alive) P.queue[base + out_count + (uint32_t)__popcll(am & ((1ull << lane) - 1ull))] = slot;
         out_count += (uint32_t)__popcll(am);
     }
     if (lane == 0) {
         P.qcount[wave] = out_count;
-        if (out_count) *Bt.alive_flag = 1u;
-        wave_stats[(size_t)wave * kWaveStatWords + ST_PATHS] += n_started;
+        if (out_count && Bt.alive_flag) Bt.alive_flag[(wave & 31u) * 32u] = 1u;  // 32 lines share the traffic
+        wave_stats[(size_t)wave * kWaveStatWords + ST_PATHS] += out_count;
     }
 }
 
+// Trail addressing: the levels of 64 neighbouring slots are kept together (level-major inside the group), so that a
+// wave's trail traffic stays inside a few kilobytes whatever the depths of its paths.
+DEV size_t trail_index(const PathState &P, uint32_t level, uint32_t slot) {
+    return ((size_t)(slot >> 6) * P.trail_levels + level) * 64u + (slot & 63u);
+}
+
+// What shade reads of one path slot
+struct SlotIn {
+    float4 A, B;
+    uint2 h;
+    uint32_t depth;
+    uint4 rng;
+    uint4 recent;  // the four most recent trail entries, newest first
+};
+DEV void load_slot(const PathState &P, bool active, uint32_t slot, SlotIn &in) {
+    if (active) {
+        in.A = P.rayA[slot]; in.B = P.rayB[slot]; in.h = P.hit[slot]; in.depth = P.depth[slot]; in.rng = P.rng[slot];
+        in.recent = P.recent[slot];
+    }
+}
+
+// Shades one tile (64 live slots) of the wave.  Returns per lane whether the path goes on (`alive`) or ended (`need`:
+// its slot wants a new path).
+template <bool MOVING, bool COUNT>
+DEV void shade_slot(const SceneDev &S, const PathState &P, const BatchDev &Bt, uint32_t slot, const SlotIn &in, bool &alive, bool &need,
+                    uint32_t &ev) {
+    const float4 A = in.A, B = in.B;
+    const uint2 h = in.h;
+    const uint32_t depth = in.depth & 0xFFFFu;       // scatters so far
+    const uint32_t trail_len = in.depth >> 16;       // of which recorded on the trail
+    const uint32_t pid = f2u(B.w);
+    const V3 o = mk(A.x, A.y, A.z), d = mk(B.x, B.y, B.z);
+    const float time = A.w;
+    float rx = 0.0f, ry = 0.0f, rz = 0.0f;  // radiance of a finished path
+    if (h.y == kPrimNone) {
+        // sky (lib.rs:66-70), then the product of attenuations innermost first (lib.rs:62).  The spheres scattered off
+        // on the way are read back from the trail, eight levels per round so that a long path costs few memory round
+        // trips.  Dielectric hits are not on the trail: their attenuation is (1,1,1) and x * 1 is x.
+        if (COUNT) ev = ST_SKY;
+        const uint32_t *tr = P.trail + trail_index(P, 0u, slot);
+        const size_t ns = 64u;  // level stride inside a 64-slot group
+        const float r = 1.0f / sqrtf(dot3(d, d));
+        const float uy = d.y * r;
+        const float t = 0.5f * (uy + 1.0f);
+        const float w = 1.0f - t;
+        rx = w + t * 0.5f;  // white.lerp(sky_blue, t) = white*(1-t) + sky_blue*t
+        ry = w + t * 0.7f;
+        rz = w + t * 1.0f;
+        // the newest four levels travel with the path state; older ones are in the trail planes
+        {
+            const uint32_t w[4] = {in.recent.x, in.recent.y, in.recent.z, in.recent.w};
+            float4 at[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; k++) at[k] = S.prim_att[k < trail_len ? w[k] : 0u];
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; k++)
+                if (k < trail_len) { rx = at[k].x * rx; ry = at[k].y * ry; rz = at[k].z * rz; }
+        }
+        uint32_t j = trail_len > 4u ? trail_len - 4u : 0u;
+        while (j > 0u) {
+            const uint32_t m = j < 8u ? j : 8u;
+            uint32_t pr[8];
+#pragma unroll
+            for (uint32_t k = 0; k < 8u; k++) pr[k] = k < m ? tr[(size_t)(j - 1u - k) * ns] : 0u;
+#pragma unroll
+            for (uint32_t half = 0; half < 8u; half += 4u) {
+                float4 at[4];
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; k++) at[k] = S.prim_att[pr[half + k]];
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; k++)
+                    if (half + k < m) { rx = at[k].x * rx; ry = at[k].y * ry; rz = at[k].z * rz; }
+            }
+            j -= m;
+        }
+        need = true;
+    } else if (depth >= Bt.max_depth) {  // lib.rs:58-60
+        if (COUNT) ev = ST_DEPTHCUT;
+        need = true;
+    } else {
+        const uint32_t prim = h.y;
+        const float t = u2f(h.x);
+        const float4 sp = S.sph[prim];
+        const uint32_t info = S.sph_info[prim];
+        const float4 mt = S.pmat[prim];
+        V3 c = mk(sp.x, sp.y, sp.z);
+        if (MOVING && (info & kInfoMovingBit)) {  // sphere.rs:61-64
+            const float4 m = S.motion[prim];
+            const float f = (S.flags & kSceneUniformTimes) ? (time - S.u_time0) / S.u_dt : (time - m.w) / S.motion_dt[prim];
+            c = add(c, scale(f, mk(m.x, m.y, m.z)));
+        }
+        // Hit record (sphere.rs:86-100)
+        const V3 p = add(o, scale(t, d));
+        const V3 pc = sub(p, c);
+        const V3 on = mk(pc.x / sp.w, pc.y / sp.w, pc.z / sp.w);
+        const bool front = dot3(d, on) < 0.0f;
+        const V3 n = front ? on : neg(on);
+        const uint32_t kind = (info >> kInfoKindShift) & 3u;
+        Rng g;
+        g.s0 = in.rng.x; g.s1 = in.rng.y; g.s2 = in.rng.z; g.s3 = in.rng.w;
+        V3 dir;
+        bool scattered = true;
+        if (kind == RRT_MAT_LAMBERTIAN) {  // materials.rs:19-35
+            if (COUNT) ev = ST_HL;
+            const V3 unit = normalized(in_unit_sphere(g));
+            dir = add(n, unit);
+            if (fabsf(dir.x) < 1e-8f && fabsf(dir.y) < 1e-8f && fabsf(dir.z) < 1e-8f) dir = n;
+        } else if (kind == RRT_MAT_METAL) {  // materials.rs:44-61
+            if (COUNT) ev = ST_HM;
+            const V3 refl = reflected(normalized(d), n);
+            const V3 s = in_unit_sphere(g);
+            dir = add(refl, scale(mt.w, s));
+            scattered = dot3(dir, n) > 0.0f;
+        } else {  // materials.rs:75-104
+            if (COUNT) ev = ST_HD;
+            const float ratio = front ? 1.0f / mt.w : mt.w;
+            const V3 ud = normalized(d);
+            const float cos_theta = fminf(dot3(neg(ud), n), 1.0f);
+            const float sin_theta = sqrtf(1.0f - (cos_theta * cos_theta));
+            bool reflect = ratio * sin_theta > 1.0f;
+            if (!reflect) reflect = reflectance(cos_theta, ratio) > gen_f32(g);  // the draw happens only here (materials.rs:89)
+            if (reflect) {
+                dir = reflected(ud, n);
+            } else {  // ultraviolet refracted()
+                const float ndi = dot3(n, ud);
+                const float k = 1.0f - ratio * ratio * (1.0f - ndi * ndi);
+                if (k < 0.0f) dir = mk(0.0f, 0.0f, 0.0f);
+                else dir = sub(scale(ratio, ud), scale(ratio * ndi + sqrtf(k), n));
+            }
+        }
+        if (scattered) {
+            P.rayA[slot] = make_float4(p.x, p.y, p.z, time);
+            P.rayB[slot] = make_float4(dir.x, dir.y, dir.z, B.w);
+            P.rayC[slot] = ray_constants(dir);
+            P.rng[slot] = make_uint4(g.s0, g.s1, g.s2, g.s3);
+            const bool on_trail = kind != RRT_MAT_DIELECTRIC;
+            P.depth[slot] = (depth + 1u) | ((trail_len + (on_trail ? 1u : 0u)) << 16);
+            if (on_trail) {
+                // the entry pushed out of the four-deep window goes to the trail planes
+                if (trail_len >= 4u) P.trail[trail_index(P, trail_len - 4u, slot)] = in.recent.w;
+                P.recent[slot] = make_uint4(prim, in.recent.x, in.recent.y, in.recent.z);
+            }
+            alive = true;
+        } else {  // lib.rs:64
+            if (COUNT) ev = (ev == ST_HM ? ST_HM : ev) | 0x100u;  // absorbed, on top of the material count
+            need = true;
+        }
+    }
+    if (need) {
+        Bt.rad[pid] = rx;
+        Bt.rad[(size_t)Bt.rad_plane + pid] = ry;
+        Bt.rad[2 * (size_t)Bt.rad_plane + pid] = rz;
+    }
+}
+
+// One wave shades its (up to) four tiles.  The live-slot list is read up front, the next tile's state is in flight
+// while the current tile is shaded, all ended paths of the wave claim their replacements with one cursor update, and
+// the live-slot list is rewritten compacted (ballot + prefix popcount) at the end.
 template <bool MOVING, bool COUNT>
 __global__ __launch_bounds__(kBlockThreads) void k_shade(SceneDev S, PathState P, BatchDev Bt, CameraDev C, uint64_t *wave_stats) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = (blockIdx.x * kBlockThreads + threadIdx.x) >> 6;
+    const uint32_t wave = P.wave_begin + ((blockIdx.x * kBlockThreads + threadIdx.x) >> 6);
     const uint32_t base = wave * kWaveSlots;
-    if (base >= P.n_slots) return;
+    if (wave >= P.wave_end) return;
     const uint32_t count = rfl(P.qcount[wave]);
     if (count == 0) return;
     const uint32_t shard = wave % Bt.n_shards;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
-    uint32_t out_count = 0, n_started = 0;
-    uint32_t c_hl = 0, c_hm = 0, c_hd = 0, c_sky = 0, c_cut = 0, c_abs = 0;
+    static_assert(kWaveSlots == 256, "four list entries per lane");
+    uint32_t q[4];
+    for (uint32_t t = 0; t < 4u; t++) q[t] = lane + 64u * t < count ? P.queue[base + lane + 64u * t] : 0u;
+    const uint32_t n_tiles = (count + 63u) >> 6;
+    uint32_t need_bits = 0, alive_bits = 0;
+    uint32_t c_ev[6] = {0, 0, 0, 0, 0, 0};  // HL, HM, HD, SKY, DEPTHCUT, ABSORBED
 
-    for (uint32_t t0 = 0; t0 < count; t0 += 64u) {
-        const uint32_t i = t0 + lane;
-        const bool active = i < count;
-        uint32_t slot = 0;
-        bool alive = false, need = false;
-        bool e_hl = false, e_hm = false, e_hd = false, e_sky = false, e_cut = false, e_abs = false;
-        if (active) {
-            slot = P.queue[base + i];
-            const float4 A = P.rayA[slot];
-            const float4 B = P.rayB[slot];
-            const uint2 h = P.hit[slot];
-            const uint32_t depth = P.depth[slot];
-            const uint32_t pid = f2u(B.w);
-            const V3 o = mk(A.x, A.y, A.z), d = mk(B.x, B.y, B.z);
-            const float time = A.w;
-            float rx = 0.0f, ry = 0.0f, rz = 0.0f;  // radiance of a finished path
-            if (h.y == kPrimNone) {
-                // sky (lib.rs:66-70), then the product of attenuations innermost first (lib.rs:62)
-                e_sky = true;
-                const float r = 1.0f / sqrtf(dot3(d, d));
-                const float uy = d.y * r;
-                const float t = 0.5f * (uy + 1.0f);
-                const float w = 1.0f - t;
-                rx = w + t * 0.5f;  // white.lerp(sky_blue, t) = white*(1-t) + sky_blue*t
-                ry = w + t * 0.7f;
-                rz = w + t * 1.0f;
-                for (uint32_t j = depth; j-- > 0u;) {
-                    const float4 att = S.prim_att[P.trail[(size_t)j * P.n_slots + slot]];
-                    rx = att.x * rx; ry = att.y * ry; rz = att.z * rz;
-                }
-                need = true;
-            } else if (depth >= Bt.max_depth) {  // lib.rs:58-60
-                e_cut = true;
-                need = true;
-            } else {
-                const uint32_t prim = h.y;
-                const float t = u2f(h.x);
-                const float4 sp = S.sph[prim];
-                const uint32_t info = S.sph_info[prim];
-                V3 c = mk(sp.x, sp.y, sp.z);
-                if (MOVING && (info & kInfoMovingBit)) {  // sphere.rs:61-64
-                    const float4 m = S.motion[prim];
-                    const float f = (S.flags & kSceneUniformTimes) ? (time - S.u_time0) / S.u_dt : (time - m.w) / S.motion_dt[prim];
-                    c = add(c, scale(f, mk(m.x, m.y, m.z)));
-                }
-                // Hit record (sphere.rs:86-100)
-                const V3 p = add(o, scale(t, d));
-                const V3 pc = sub(p, c);
-                const V3 on = mk(pc.x / sp.w, pc.y / sp.w, pc.z / sp.w);
-                const bool front = dot3(d, on) < 0.0f;
-                const V3 n = front ? on : neg(on);
-                const uint32_t kind = (info >> kInfoKindShift) & 3u;
-                const float4 mt = S.mat[info & kInfoMatMask];
-                Rng g;
-                { const uint4 r = P.rng[slot]; g.s0 = r.x; g.s1 = r.y; g.s2 = r.z; g.s3 = r.w; }
-                V3 dir;
-                bool scattered = true;
-                if (kind == RRT_MAT_LAMBERTIAN) {  // materials.rs:19-35
-                    e_hl = true;
-                    const V3 unit = normalized(in_unit_sphere(g));
-                    dir = add(n, unit);
-                    if (fabsf(dir.x) < 1e-8f && fabsf(dir.y) < 1e-8f && fabsf(dir.z) < 1e-8f) dir = n;
-                } else if (kind == RRT_MAT_METAL) {  // materials.rs:44-61
-                    e_hm = true;
-                    const V3 refl = reflected(normalized(d), n);
-                    const V3 s = in_unit_sphere(g);
-                    dir = add(refl, scale(mt.w, s));
-                    scattered = dot3(dir, n) > 0.0f;
-                } else {  // materials.rs:75-104
-                    e_hd = true;
-                    const float ratio = front ? 1.0f / mt.w : mt.w;
-                    const V3 ud = normalized(d);
-                    const float cos_theta = fminf(dot3(neg(ud), n), 1.0f);
-                    const float sin_theta = sqrtf(1.0f - (cos_theta * cos_theta));
-                    bool reflect = ratio * sin_theta > 1.0f;
-                    if (!reflect) reflect = reflectance(cos_theta, ratio) > gen_f32(g);  // the draw happens only here (materials.rs:89)
-                    if (reflect) {
-                        dir = reflected(ud, n);
-                    } else {  // ultraviolet refracted()
-                        const float ndi = dot3(n, ud);
-                        const float k = 1.0f - ratio * ratio * (1.0f - ndi * ndi);
-                        if (k < 0.0f) dir = mk(0.0f, 0.0f, 0.0f);
-                        else dir = sub(scale(ratio, ud), scale(ratio * ndi + sqrtf(k), n));
-                    }
-                }
-                if (scattered) {
-                    P.rayA[slot] = make_float4(p.x, p.y, p.z, time);
-                    P.rayB[slot] = make_float4(dir.x, dir.y, dir.z, B.w);
-                    P.rng[slot] = make_uint4(g.s0, g.s1, g.s2, g.s3);
-                    P.depth[slot] = depth + 1u;
-                    P.trail[(size_t)depth * P.n_slots + slot] = prim;
-                    alive = true;
-                } else {  // lib.rs:64
-                    e_abs = true;
-                    need = true;
-                }
+    SlotIn cur, nxt;
+    load_slot(P, lane < count, q[0], cur);
+#pragma unroll
+    for (uint32_t t = 0; t < 4u; t++) {
+        if (t < n_tiles) {
+            if (t + 1u < 4u) load_slot(P, lane + 64u * (t + 1u) < count, q[(t + 1u) & 3u], nxt);
+            bool alive = false, need = false;
+            uint32_t ev = 0xFFu;
+            if (lane + 64u * t < count) shade_slot<MOVING, COUNT>(S, P, Bt, q[t], cur, alive, need, ev);
+            need_bits |= need ? (1u << t) : 0u;
+            alive_bits |= alive ? (1u << t) : 0u;
+            if (COUNT) {
+                const uint32_t e = ev & 0xFFu;
+                c_ev[0] += (uint32_t)__popcll(__ballot(e == ST_HL)); c_ev[1] += (uint32_t)__popcll(__ballot(e == ST_HM));
+                c_ev[2] += (uint32_t)__popcll(__ballot(e == ST_HD)); c_ev[3] += (uint32_t)__popcll(__ballot(e == ST_SKY));
+                c_ev[4] += (uint32_t)__popcll(__ballot(e == ST_DEPTHCUT)); c_ev[5] += (uint32_t)__popcll(__ballot((ev & 0x100u) != 0u));
             }
-            if (need) {
-                Bt.rad[pid] = rx;
-                Bt.rad[(size_t)Bt.rad_plane + pid] = ry;
-                Bt.rad[2 * (size_t)Bt.rad_plane + pid] = rz;
-            }
+            cur = nxt;
         }
-        if (COUNT) {
-            c_hl += (uint32_t)__popcll(__ballot(e_hl)); c_hm += (uint32_t)__popcll(__ballot(e_hm));
-            c_hd += (uint32_t)__popcll(__ballot(e_hd)); c_sky += (uint32_t)__popcll(__ballot(e_sky));
-            c_cut += (uint32_t)__popcll(__ballot(e_cut)); c_abs += (uint32_t)__popcll(__ballot(e_abs));
+    }
+    // ended paths: their slots take the next paths of the batch, if any are left
+    uint32_t n_need = 0;
+    for (uint32_t t = 0; t < 4u; t++) n_need += (uint32_t)__popcll(__ballot((need_bits >> t) & 1u));
+    uint32_t n_started = 0;
+    if (n_need) {
+        uint32_t n = claim_paths(Bt, lane, shard, n_need);
+        for (uint32_t t = 0; t < 4u; t++) {
+            const bool need = (need_bits >> t) & 1u;
+            const uint64_t nm = __ballot(need);
+            if (nm == 0ull) continue;
+            bool started = false;
+            if (need) started = start_path(P, Bt, C, shard, n + (uint32_t)__popcll(nm & lt_mask), q[t]);
+            alive_bits |= started ? (1u << t) : 0u;
+            n_started += (uint32_t)__popcll(__ballot(started));
+            n += (uint32_t)__popcll(nm);
         }
-        // a finished path's slot takes the next path of the batch, if any is left
-        regenerate(P, Bt, C, lane, shard, need, slot, alive, n_started);
-        // compaction of the wave's live-slot list, in place: writes never pass the entries still to be read
+    }
+    // compaction of the wave's live-slot list
+    uint32_t out_count = 0;
+    for (uint32_t t = 0; t < 4u; t++) {
+        const bool alive = (alive_bits >> t) & 1u;
         const uint64_t am = __ballot(alive);
-        if (alive) P.queue[base + out_count + (uint32_t)__popcll(am & lt_mask)] = slot;
+        if (alive) P.queue[base + out_count + (uint32_t)__popcll(am & lt_mask)] = q[t];
         out_count += (uint32_t)__popcll(am);
     }
     if (lane == 0) {
         P.qcount[wave] = out_count;
-        if (out_count) *Bt.alive_flag = 1u;
+        if (out_count && Bt.alive_flag) Bt.alive_flag[(wave & 31u) * 32u] = 1u;  // 32 lines share the traffic
         uint64_t *st = wave_stats + (size_t)wave * kWaveStatWords;
         st[ST_PATHS] += n_started;
         if (COUNT) {
-            st[ST_HL] += c_hl; st[ST_HM] += c_hm; st[ST_HD] += c_hd; st[ST_SKY] += c_sky;
-            st[ST_DEPTHCUT] += c_cut; st[ST_ABSORBED] += c_abs;
+            st[ST_HL] += c_ev[0]; st[ST_HM] += c_ev[1]; st[ST_HD] += c_ev[2]; st[ST_SKY] += c_ev[3];
+            st[ST_DEPTHCUT] += c_ev[4]; st[ST_ABSORBED] += c_ev[5];
         }
     }
 }
@@ -548,12 +715,17 @@ __global__ void k_intersect(SceneDev S, uint32_t n, const float *org, const floa
                             float *out_t, uint32_t *out_obj) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float tmax = t_max;
-    uint32_t best = kPrimNone, ni = 0, nl = 0;
-    traverse<MOVING, false>(S, mk(org[i * 3u], org[i * 3u + 1u], org[i * 3u + 2u]), mk(dir[i * 3u], dir[i * 3u + 1u], dir[i * 3u + 2u]),
-                            time ? time[i] : 0.0f, t_min, tmax, best, ni, nl);
-    out_t[i] = tmax;
-    out_obj[i] = best;
+    const HbmStore<MOVING> st(S);
+    RayCtx r;
+    ray_setup(r, make_float4(org[i * 3u], org[i * 3u + 1u], org[i * 3u + 2u], time ? time[i] : 0.0f),
+              make_float4(dir[i * 3u], dir[i * 3u + 1u], dir[i * 3u + 2u], 0.0f), t_min, t_max, S, st.uniform_times());
+    uint32_t cur = st.root();
+    while (cur != HbmStore<MOVING>::kEnd) {
+        while (cur < HbmStore<MOVING>::kEnd) cur = visit_inner(st, cur, r);
+        if (cur != HbmStore<MOVING>::kEnd) cur = visit_leaf(st, cur, r);
+    }
+    out_t[i] = r.tmax;
+    out_obj[i] = r.best;
 }
 
 __global__ void k_reduce_stats(const uint64_t *wave_stats, uint32_t n_waves, uint64_t *out16) {
@@ -570,7 +742,7 @@ __global__ void k_reduce_stats(const uint64_t *wave_stats, uint32_t n_waves, uin
     if (threadIdx.x == 0) out16[k] = part[0];
 }
 
-inline uint32_t wave_grid(const PathState &P) { return (P.n_slots / kWaveSlots + 3u) / 4u; }
+inline uint32_t wave_grid(const PathState &P) { return (P.wave_end - P.wave_begin + 3u) / 4u; }
 
 }  // namespace
 
@@ -578,27 +750,28 @@ void launch_raygen(hipStream_t s, const PathState &P, const BatchDev &B, const C
     hipLaunchKernelGGL(k_raygen, dim3(wave_grid(P)), dim3(kBlockThreads), 0, s, P, B, C, wave_stats);
 }
 
-void launch_extend(hipStream_t s, const SceneDev &S, const PathState &P, bool moving, bool count, uint64_t *wave_stats) {
+void launch_extend(hipStream_t s, const SceneDev &S, const PathState &P, bool moving, bool count, uint32_t retire_min,
+                   uint32_t leaf_min, uint64_t *wave_stats) {
     if (S.small_nodes) {  // scene fits in LDS
         const uint32_t waves_per_block = kLdsBlockThreads / 64u;
-        const dim3 g((P.n_slots / kWaveSlots + waves_per_block - 1u) / waves_per_block), b(kLdsBlockThreads);
+        const dim3 g((P.wave_end - P.wave_begin + waves_per_block - 1u) / waves_per_block), b(kLdsBlockThreads);
         const size_t lds = (size_t)S.n_nodes * S.small_words * 4u;
         if (moving) {
-            if (count) hipLaunchKernelGGL((k_extend_lds<true, true>), g, b, lds, s, S, P, wave_stats);
-            else hipLaunchKernelGGL((k_extend_lds<true, false>), g, b, lds, s, S, P, wave_stats);
+            if (count) hipLaunchKernelGGL((k_extend_lds<true, true>), g, b, lds, s, S, P, retire_min, leaf_min, wave_stats);
+            else hipLaunchKernelGGL((k_extend_lds<true, false>), g, b, lds, s, S, P, retire_min, leaf_min, wave_stats);
         } else {
-            if (count) hipLaunchKernelGGL((k_extend_lds<false, true>), g, b, lds, s, S, P, wave_stats);
-            else hipLaunchKernelGGL((k_extend_lds<false, false>), g, b, lds, s, S, P, wave_stats);
+            if (count) hipLaunchKernelGGL((k_extend_lds<false, true>), g, b, lds, s, S, P, retire_min, leaf_min, wave_stats);
+            else hipLaunchKernelGGL((k_extend_lds<false, false>), g, b, lds, s, S, P, retire_min, leaf_min, wave_stats);
         }
         return;
     }
     const dim3 g(wave_grid(P)), b(kBlockThreads);
     if (moving) {
-        if (count) hipLaunchKernelGGL((k_extend<true, true>), g, b, 0, s, S, P, wave_stats);
-        else hipLaunchKernelGGL((k_extend<true, false>), g, b, 0, s, S, P, wave_stats);
+        if (count) hipLaunchKernelGGL((k_extend<true, true>), g, b, 0, s, S, P, retire_min, leaf_min, wave_stats);
+        else hipLaunchKernelGGL((k_extend<true, false>), g, b, 0, s, S, P, retire_min, leaf_min, wave_stats);
     } else {
-        if (count) hipLaunchKernelGGL((k_extend<false, true>), g, b, 0, s, S, P, wave_stats);
-        else hipLaunchKernelGGL((k_extend<false, false>), g, b, 0, s, S, P, wave_stats);
+        if (count) hipLaunchKernelGGL((k_extend<false, true>), g, b, 0, s, S, P, retire_min, leaf_min, wave_stats);
+        else hipLaunchKernelGGL((k_extend<false, false>), g, b, 0, s, S, P, retire_min, leaf_min, wave_stats);
     }
 }
 

@@ -42,7 +42,7 @@ int build_scene_layout(const rrt_sphere_soa *sp, const rrt_material_soa *mt, con
     }
 
     // ---- spheres ----
-    out.sph.resize(ns); out.motion.resize(ns); out.motion_dt.resize(ns); out.sph_info.resize(ns); out.prim_att.resize(ns);
+    out.sph.resize(ns); out.motion.resize(ns); out.motion_dt.resize(ns); out.sph_info.resize(ns); out.prim_att.resize(ns); out.pmat.resize(ns);
     bool any_moving = false, uniform = true;
     uint32_t ut0 = 0, ut1 = 0;
     for (uint32_t i = 0; i < ns; i++) {
@@ -59,6 +59,7 @@ int build_scene_layout(const rrt_sphere_soa *sp, const rrt_material_soa *mt, con
         out.motion[i] = Float4{c1[0] - c0[0], c1[1] - c0[1], c1[2] - c0[2], sp->time0[i]};
         out.motion_dt[i] = sp->time1[i] - sp->time0[i];
         out.sph_info[i] = m | (mt->kind[m] << kInfoKindShift) | (still ? 0u : kInfoMovingBit);
+        out.pmat[i] = out.mat[m];
         if (mt->kind[m] == RRT_MAT_DIELECTRIC) out.prim_att[i] = Float4{1.f, 1.f, 1.f, 0.f};
         else out.prim_att[i] = Float4{mt->albedo_r[m], mt->albedo_g[m], mt->albedo_b[m], 1.f};
         if (!still) {
@@ -110,7 +111,7 @@ int build_scene_layout(const rrt_sphere_soa *sp, const rrt_material_soa *mt, con
             w[4] = p;
             w[5] = (out.sph_info[p] & kInfoMovingBit) ? 1u : 0u;
         } else {
-            for (int k = 0; k < 3; k++) { w[k] = f2u(n.min[k]); w[3 + k] = f2u(n.max[k]); }
+            for (int k = 0; k < 3; k++) { w[2 * k] = f2u(n.min[k]); w[2 * k + 1] = f2u(n.max[k]); }
             const uint32_t axis = (n.right_axis_leaf >> RRT_NODE_AXIS_SHIFT) & 3u;
             w[6] = ref_of(n.right_axis_leaf & RRT_NODE_INDEX_MASK) | (axis << RRT_NODE_AXIS_SHIFT);
             w[7] = ref_of(n.left_or_obj);

@@ -39,7 +39,7 @@ constexpr uint32_t kSceneUniformTimes = 2u;
 struct Float4 { float x, y, z, w; };
 
 struct SceneLayout {
-    // Node words.  Inner: [0..2] box min, [3..5] box max, [6] right ref | axis << 29, [7] left ref,
+    // Node words.  Inner: [0..5] box as (min, max) per axis: x, y, z, [6] right ref | axis << 29, [7] left ref,
     // [8..15] exit link per octant.  Leaf: [0..2] centre at time0, [3] radius^2, [4] sphere index,
     // [5] bit 0 = moving, [8..15] exit link per octant.
     std::vector<uint32_t> nodes;
@@ -47,8 +47,8 @@ struct SceneLayout {
     uint32_t root_ref = kRefEnd;
     uint32_t max_leaf_depth = 0;
 
-    // Compact node words (empty when the scene does not qualify).  [0..3] inner: min xyz, max x; leaf: centre,
-    // radius^2.  [4..5] inner: max y, max z; leaf: sphere index, moving flag.  [6] inner: left ref16 | right
+    // Compact node words (empty when the scene does not qualify).  [0..5] inner: (min, max) per axis; leaf: centre,
+    // radius^2, sphere index, moving flag.  [6] inner: left ref16 | right
     // ref16 << 16.  [7] inner: axis.  [8..11] eight 16-bit exit links.  [12..14] (moving scenes) centre1 - centre0.
     std::vector<uint32_t> small_nodes;
     uint32_t small_words = 0;
@@ -59,6 +59,7 @@ struct SceneLayout {
     std::vector<float> motion_dt;   // time1 - time0
     std::vector<uint32_t> sph_info; // see kInfo*
     std::vector<Float4> mat;        // {albedo rgb, fuzz or ref_idx}
+    std::vector<Float4> pmat;       // mat[material of sphere i]
     std::vector<Float4> prim_att;   // attenuation of a scatter off this sphere (materials.rs:32,55,101)
     uint32_t n_spheres = 0;
     uint32_t flags = 0;

@@ -217,6 +217,31 @@ def test_custom_scene_general_motion(gpu_ctx):
         assert_same_image(gpu, ref)
 
 
+def test_long_paths_between_two_walls(gpu_ctx):
+    """A narrow gap between two huge diffuse/metal spheres: paths scatter dozens of times before they see the sky, so the
+    back-to-front product of attenuations (lib.rs:62) runs over long trails, and some paths reach the depth limit."""
+    sp = np.zeros((3, 9), np.float32)
+    sp[0, 0:3] = sp[0, 3:6] = (-1000.06, 0.0, 0.0)
+    sp[1, 0:3] = sp[1, 3:6] = (1000.06, 0.0, 0.0)
+    sp[2, 0:3] = sp[2, 3:6] = (0.0, 0.0, -3.0)
+    sp[:, 7] = 1.0
+    sp[:, 8] = (1000.0, 1000.0, 0.05)
+    mt = np.array([[0, 0.9, 0.8, 0.7, 0, 0], [1, 0.95, 0.9, 0.85, 0.05, 0], [2, 1, 1, 1, 0, 1.5]], np.float32)
+    mid = np.arange(3, dtype=np.uint32)
+    cam = rrt_amd.camera_from((0, 0.5, 2), (0, 0, -3), (0, 1, 0), 30.0, 1.0, 0.0, 1.0, 0.0, 0.0)
+    osc = OracleScene.from_arrays(sp, mid, mt, np.zeros((0, 8), np.uint32), cam.as_array())
+    osc.build_bvh(0)
+    _, _, _, nd, _ = scene_arrays_from_oracle(osc)
+    gpu_ctx.upload_scene(sp, mid, mt, nd)
+    gpu_ctx.set_camera(cam)
+    nx, ny, ns = 48, 48, 8
+    ref = osc.render(nx, ny, ns, seed=8, threads=8)
+    gpu = gpu_ctx.render(rrt_amd.Context.params(nx, ny, ns, seed=8, count_work=True))
+    assert_same_image(gpu, ref)
+    assert ref[2]["rays"] / ref[2]["paths"] > 8 and ref[2]["depth_cut"] > 0 and ref[2]["sky_misses"] > 100
+    assert gpu[2]["depth_cut"] == ref[2]["depth_cut"]
+
+
 def test_tracescene_mirror(gpu_ctx):
     """The reference's call sequence end to end: chap12_scene -> init_pool_with_rng -> tracescene (benches/benchmark.rs:14-23)."""
     nx, ny, ns = 10, 10, 4
