@@ -44,8 +44,8 @@ struct DevBuf {
     template <class T> T *as() const { return static_cast<T *>(p); }
 };
 
-constexpr uint32_t kDefaultSlots = 1u << 21;
-constexpr size_t kRadBudgetBytes = size_t(3) << 30;
+constexpr uint32_t kDefaultSlots = 1u << 22;
+constexpr size_t kRadBudgetBytes = size_t(16) << 30;  // per-batch radiance planes; HBM is 288 GB
 constexpr uint32_t kMaxBatchPaths = 1u << 30;
 constexpr uint32_t kFlagWords = 2 * 32 * 32;  // per half: 32 flag words, one per 128-byte line
 constexpr uint32_t kChunk = 8;  // extend+shade rounds queued between two looks at the alive flag
@@ -297,7 +297,8 @@ int render_impl(rrt_ctx *c, const rrt_render_params *pp, void *d_rgb8, void *d_a
         // (VALU-bound) always runs beside the shade kernel of the other half (bound by memory latency).
         const char *env_streams = std::getenv("RRT_STREAMS");
         const uint32_t n_half = (n_waves >= 64 && !(env_streams && env_streams[0] == '1')) ? 2u : 1u;
-        hipStream_t s_ext = s, s_shd = n_half == 2 ? c->stream2 : s;
+        const bool free_run = !(env_streams && env_streams[0] == '2');  // '2': alternate the halves strictly through events (slower)
+        hipStream_t s_ext0 = s, s_shd0 = n_half == 2 ? c->stream2 : s;
         PathState half[2] = {ps, ps};
         if (n_half == 2) { half[0].wave_end = n_waves / 2; half[1].wave_begin = n_waves / 2; }
 
@@ -317,25 +318,26 @@ int render_impl(rrt_ctx *c, const rrt_render_params *pp, void *d_rgb8, void *d_a
             launch_raygen(s, ps, bd, c->cam, wstats);
             for (;;) {
                 HIP_TRY(hipMemsetAsync(flags, 0, kFlagWords * 4, s));
-                if (n_half == 2) { HIP_TRY(hipEventRecord(c->ev_fork, s)); HIP_TRY(hipStreamWaitEvent(s_shd, c->ev_fork, 0)); }
+                if (n_half == 2) { HIP_TRY(hipEventRecord(c->ev_fork, s)); HIP_TRY(hipStreamWaitEvent(s_shd0, c->ev_fork, 0)); }
                 for (uint32_t it = 0; it < kChunk; it++) {
                     for (uint32_t h = 0; h < n_half; h++) {
-                        if (n_half == 2 && it > 0) HIP_TRY(hipStreamWaitEvent(s_ext, c->ev_shd[h], 0));  // the half's previous shade
+                        hipStream_t s_ext = free_run ? (h ? s_shd0 : s_ext0) : s_ext0, s_shd = free_run ? s_ext : s_shd0;
+                        if (n_half == 2 && it > 0 && !free_run) HIP_TRY(hipStreamWaitEvent(s_ext, c->ev_shd[h], 0));  // the half's previous shade
                         if (time_kernels) {
                             while (c->kev.size() < kev_used + 2) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); c->kev.push_back(ev); }
                             HIP_TRY(hipEventRecord(c->kev[kev_used], s_ext));
                         }
                         launch_extend(s_ext, sd, half[h], c->moving, count, retire_min, leaf_min, wstats);
                         if (time_kernels) { HIP_TRY(hipEventRecord(c->kev[kev_used + 1], s_ext)); kev_used += 2; }
-                        if (n_half == 2) { HIP_TRY(hipEventRecord(c->ev_ext[h], s_ext)); HIP_TRY(hipStreamWaitEvent(s_shd, c->ev_ext[h], 0)); }
+                        if (n_half == 2 && !free_run) { HIP_TRY(hipEventRecord(c->ev_ext[h], s_ext)); HIP_TRY(hipStreamWaitEvent(s_shd, c->ev_ext[h], 0)); }
                         bd.alive_flag = it + 1 == kChunk ? flags + h * 1024 : nullptr;  // only the chunk's last round reports
                         launch_shade(s_shd, sd, half[h], bd, c->cam, c->moving, count, wstats);
-                        if (n_half == 2) HIP_TRY(hipEventRecord(c->ev_shd[h], s_shd));
+                        if (n_half == 2 && !free_run) HIP_TRY(hipEventRecord(c->ev_shd[h], s_shd));
                     }
                 }
                 st.iterations += kChunk;
                 HIP_TRY(hipGetLastError());
-                if (n_half == 2) { HIP_TRY(hipEventRecord(c->ev_join, s_shd)); HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0)); }
+                if (n_half == 2) { HIP_TRY(hipEventRecord(c->ev_join, s_shd0)); HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0)); }
                 HIP_TRY(hipMemcpyAsync(c->h_flags, flags, kFlagWords * 4, hipMemcpyDeviceToHost, s));
                 HIP_TRY(hipStreamSynchronize(s));
                 uint32_t any = 0;
