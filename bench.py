@@ -3,18 +3,19 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One step = one full render of the workload: chap12 scene (seed 0, 484 spheres / 967 BVH nodes),
-1200x800 pixels, 500 samples per pixel, depth 50 — every primary ray, BVH walk, sphere test, scatter
-and the framebuffer accumulation/quantisation.  Rays = calls of Bvh::hit (lib.rs:57), counted on the
-device.  The scene is uploaded before the timed region; the image stays in HBM.
+One step = one full render of the workload: chap12 scene (seed 0, 484 spheres / 967 BVH nodes), 1200x800 pixels,
+500 samples per pixel, depth 50 — every primary ray, BVH walk, sphere test, scatter, and the framebuffer accumulation
+and quantisation.  Rays = calls of Bvh::hit (lib.rs:57), counted on the device.  The scene is uploaded before the timed
+region; the image stays in HBM.
 
-N > 1 (one process per GPU, torch.distributed over RCCL): weak scaling by sample sharding — the job
-is the same image at 500*N samples per pixel, rank r renders samples k = r (mod N) and the f32
-framebuffers are summed onto rank 0 with one reduce over xGMI, then quantised there.
+N > 1 (one process per GPU, torch.distributed over RCCL): weak scaling by sample sharding — the job is the same image at
+500*N samples per pixel, rank r renders samples k = r (mod N), the f32 framebuffers are summed onto rank 0 with one
+reduce over xGMI and quantised there (rrt_amd/multi.py).
 
-Rank 0 prints one JSON line.  `roofline` prices the extend kernel (BVH walk + sphere quadratic)
-against the FP32 vector peak; `cpu_baseline` is the C restatement of the reference's threaded CPU
-renderer (oracle/) on a bounded sample of the same workload, on this box's host cores.
+Rank 0 prints one JSON line.  `roofline` prices the extend kernel (BVH walk + sphere quadratic) against the FP32 vector
+peak, with launch durations from HIP events around every extend launch of the timed steps and work counters from one
+extra pass of the counting build of the same kernels (same seeds, deterministic).  `cpu_baseline` is the C restatement
+of the reference's threaded CPU renderer (oracle/) on a bounded sample of the same workload, on this box's host cores.
 """
 import argparse
 import json
@@ -26,23 +27,23 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 NX, NY, NS, MAX_DEPTH, SEED = 1200, 800, 500, 50, 0
-FP32_VECTOR_PEAK_TFLOPS = 157.3   # 256 CU x 4 SIMD x 32 lanes x 2 (packed) x 2 (fma) x 2.4 GHz
+FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X: 256 CU x 4 SIMD x 16 lanes x 2 (packed) x 2 (fma) x 2.4 GHz
 HBM_PEAK_GBS = 8000.0
 
 
 def extend_flops(st):
-    """Algorithmic FLOPs of the extend kernel: 3 divisions for 1/direction per ray, 22 per slab test, 39 per sphere test."""
-    return 3 * st["rays"] + 22 * st["inner_visits"] + 39 * st["leaf_tests"]
+    """Algorithmic FLOPs of the extend kernel: 22 per slab test (acceleration.rs:60-84) and 39 per sphere test
+    (sphere.rs:68-85).  1/direction and direction.direction are computed where a ray is made, not here."""
+    return 22 * st["inner_visits"] + 39 * st["leaf_tests"]
 
 
 def extend_bytes(st):
-    """Algorithmic bytes of the extend kernel: 32 B box+topology per inner visit, 36 B per sphere test,
-    ray in (32 B + 4 B list entry) and hit out (8 B) per ray."""
-    return 32 * st["inner_visits"] + 36 * st["leaf_tests"] + 44 * st["rays"]
+    """Algorithmic bytes the extend kernel moves to and from HBM: per ray 48 B of ray state + 4 B list entry in, 8 B hit
+    out.  (The BVH — 32 B per box test, 16 B per sphere test — is read from the LDS copy, not from HBM.)"""
+    return 60 * st["rays"]
 
 
 def cpu_baseline(ns_sample=16):
-    import numpy as np  # noqa: F401
     from oracle import MODE_REF_POOL, OracleScene
 
     threads = min(16, os.cpu_count() or 1)
@@ -53,7 +54,8 @@ def cpu_baseline(ns_sample=16):
     dt = time.perf_counter() - t0
     return {"value": round(ctr["rays"] / dt / 1e6, 2), "unit": "Mrays/s", "cores": threads, "kind": "port",
             "sample": f"chap12 {NX}x{NY}, {ns_sample} of {NS} spp, depth {MAX_DEPTH}, seed {SEED}: {ctr['rays']} rays in {dt:.2f} s; "
-                      "C restatement of the reference CPU path (per-thread jumped Xoshiro128+, dynamic pixel scheduling), scene build excluded"}
+                      "C restatement of the reference CPU path (recursive trace, per-thread jumped Xoshiro128+, pixels claimed "
+                      "dynamically, libm powf), scene build excluded; the Rust reference itself cannot be built here"}
 
 
 def main():
@@ -64,26 +66,32 @@ def main():
     ap.add_argument("--spp", type=int, default=NS, help="samples per pixel per GPU (the headline workload is 500)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="process-group backend; gloo + RRT_BENCH_ONE_DEVICE=1 rehearses N > 1 on a 1-GPU box")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
 
     import rrt_amd
+    from rrt_amd import multi
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if world == 1 and args.gpus > 1:
+        raise SystemExit("launch with `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    if os.environ.get("RRT_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0  # rehearsal: every rank shares GPU 0 (not a scaling measurement)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     ctx = rrt_amd.Context(local_rank)
     scene = rrt_amd.HostScene(rrt_amd.SCENE_CHAP12, NX, NY, seed=SEED)
@@ -93,21 +101,23 @@ def main():
     accum = torch.zeros(NY * NX * 3, dtype=torch.float32, device=dev)
     rgb8 = torch.zeros(NY * NX * 3, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
+    flags = {"count": False, "timed": False}
 
-    def params(count=False, timed=False):
-        if world == 1:
-            return rrt_amd.Context.params(NX, NY, ns_total, seed=SEED, max_depth=MAX_DEPTH, count_work=count, time_kernels=timed)
-        return rrt_amd.Context.params(NX, NY, ns_total, seed=SEED, max_depth=MAX_DEPTH, shard_mode=rrt_amd.SHARD_SAMPLE, rank=rank,
-                                      world=world, count_work=count, time_kernels=timed)
+    def render_fn(p):
+        p.count_work = int(flags["count"])
+        p.reserved[0] = int(flags["timed"])
+        st = ctx.render_device(p, rgb8.data_ptr() if world == 1 else 0, accum.data_ptr())
+        return rgb8, accum, st
+
+    def finalize(acc, ns):
+        torch.cuda.synchronize()
+        ctx.finalize(acc.data_ptr(), NX * NY, ns, rgb8.data_ptr())
+        return rgb8
 
     def step(count=False, timed=False):
-        if world == 1:
-            return ctx.render_device(params(count, timed), rgb8.data_ptr(), accum.data_ptr())
-        st = ctx.render_device(params(count, timed), 0, accum.data_ptr())
-        dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)      # framebuffer combine over xGMI
-        if rank == 0:
-            torch.cuda.synchronize()
-            ctx.finalize(accum.data_ptr(), NX * NY, ns_total, rgb8.data_ptr())
+        flags["count"], flags["timed"] = count, timed
+        _, _, st = multi.render_sharded(render_fn, NX, NY, ns_total, SEED, rrt_amd.SHARD_SAMPLE, rank, world, dst=0, finalize=finalize,
+                                        max_depth=MAX_DEPTH)
         return st
 
     def fence():
@@ -120,10 +130,7 @@ def main():
         step()
     fence()
     t0 = time.perf_counter()
-    rays_local = 0
-    ext_ms = 0.0
-    ext_launches = 0
-    gpu_ms = 0.0
+    rays_local, ext_ms, ext_launches, gpu_ms = 0, 0.0, 0, 0.0
     for _ in range(args.steps):
         st = step(timed=not args.no_roofline)
         rays_local += st["rays"]
@@ -133,6 +140,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
 
+    rays_total = rays_local
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -140,32 +148,25 @@ def main():
         r = torch.tensor([rays_local], dtype=torch.int64, device=dev)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
         rays_total = int(r.item())
-    else:
-        rays_total = rays_local
 
     roofline = None
-    if not args.no_roofline and rank == 0:
-        # Work counters come from one more pass of the counting build of the same kernels on the same seeds
-        # (deterministic); launch durations come from HIP events around every extend launch of the timed steps.
-        cst = step(count=True)
-        flops = extend_flops(cst) * args.steps
-        byts = extend_bytes(cst) * args.steps
-        achieved = flops / (ext_ms * 1e-3) / 1e12 if ext_ms > 0 else 0.0
-        roofline = {
-            "kernel": "k_extend", "bound": "valu_fp32", "achieved": round(achieved, 3), "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / FP32_VECTOR_PEAK_TFLOPS, 4), "traffic": None,
-            "launches": ext_launches, "avg_launch_ms": round(ext_ms / max(1, ext_launches), 4),
-            "flop_per_launch": round(flops / max(1, ext_launches)),
-            "hbm": {"achieved": round(byts / (ext_ms * 1e-3) / 1e9, 1) if ext_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(byts / (ext_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ext_ms > 0 else 0.0},
-            "extend_share_of_gpu_time": round(ext_ms / gpu_ms, 3) if gpu_ms > 0 else None,
-            "per_ray": {"inner_visits": round(cst["inner_visits"] / cst["rays"], 2), "leaf_tests": round(cst["leaf_tests"] / cst["rays"], 2),
-                        "rays_per_path": round(cst["rays"] / cst["paths"], 3)},
-        }
-    elif world > 1:
-        step(count=False)  # keep every rank in the collective of rank 0's extra pass
-    if world > 1 and not args.no_roofline and rank != 0:
-        pass
+    if not args.no_roofline:
+        cst = step(count=True)  # every rank takes part (the pass ends in the same reduce); rank 0 reports its own counters
+        if rank == 0 and ext_ms > 0:
+            flops = extend_flops(cst) * args.steps
+            byts = extend_bytes(cst) * args.steps
+            sec = ext_ms * 1e-3
+            roofline = {
+                "kernel": "k_extend_lds", "bound": "valu_fp32", "achieved": round(flops / sec / 1e12, 3), "peak": FP32_VECTOR_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(flops / sec / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 4), "traffic": None,
+                "launches": ext_launches, "avg_launch_ms": round(ext_ms / max(1, ext_launches), 4),
+                "flop_per_launch": round(flops / max(1, ext_launches)),
+                "note": "extend launches of the two halves of the path pool run on two streams and overlap each other and the shade "
+                        "kernel, so the summed launch durations exceed wall time and `achieved` is a lower bound",
+                "hbm": {"achieved": round(byts / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(byts / sec / 1e9 / HBM_PEAK_GBS, 4)},
+                "per_ray": {"inner_visits": round(cst["inner_visits"] / cst["rays"], 2), "leaf_tests": round(cst["leaf_tests"] / cst["rays"], 2),
+                            "rays_per_path": round(cst["rays"] / cst["paths"], 3)},
+            }
 
     if rank == 0:
         out = {
