@@ -156,9 +156,15 @@ def main():
             flops = extend_flops(cst) * args.steps
             byts = extend_bytes(cst) * args.steps
             sec = ext_ms * 1e-3
+            traffic = None
+            try:  # HBM bytes per extend launch from separate rocprofv3 --pmc passes (profiles/README.md)
+                with open(os.path.join(ROOT, "profiles", "extend_traffic.json")) as f:
+                    traffic = json.load(f)["bytes_per_launch"]
+            except (OSError, KeyError, ValueError):
+                pass
             roofline = {
                 "kernel": "k_extend_lds", "bound": "valu_fp32", "achieved": round(flops / sec / 1e12, 3), "peak": FP32_VECTOR_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(flops / sec / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(flops / sec / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 4), "traffic": traffic,
                 "launches": ext_launches, "avg_launch_ms": round(ext_ms / max(1, ext_launches), 4),
                 "flop_per_launch": round(flops / max(1, ext_launches)),
                 "note": "extend launches of the two halves of the path pool run on two streams and overlap each other and the shade "
