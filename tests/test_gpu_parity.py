@@ -298,3 +298,33 @@ def test_full_chap12_1200x800x500_spot(gpu_ctx):
 
 def test_full_book2chap2_1200x800_spot(gpu_ctx):
     spot_check(gpu_ctx, SCENES["book2chap2"], 1200, 800, 100, seed=0, n_pixels=64)
+
+
+def test_large_scene_walks_the_hbm_bvh(gpu_ctx):
+    """14 k spheres do not fit the LDS copy: the 64-byte linked nodes are walked in HBM.  Host-built scene on the GPU,
+    oracle-built scene on the CPU (the builders agree bit for bit, tests/test_host_mirror.py)."""
+    nx, ny, ns, half = 96, 54, 4, 60
+    hs = rrt_amd.HostScene(rrt_amd.SCENE_RANDOM_SPHERES, nx, ny, seed=0, half=half)
+    assert hs.n_nodes * 64 > 64 * 1024
+    gpu_ctx.upload_host_scene(hs)
+    osc = OracleScene.build(rrt_amd.SCENE_RANDOM_SPHERES, nx, ny, seed=0, half=half)
+    ref = osc.render(nx, ny, ns, seed=6, threads=8)
+    gpu = gpu_ctx.render(rrt_amd.Context.params(nx, ny, ns, seed=6, count_work=True))
+    assert_same_image(gpu, ref)
+    assert gpu[2]["inner_visits"] == ref[2]["inner_visits"] and gpu[2]["leaf_tests"] == ref[2]["leaf_tests"]
+
+
+def test_million_sphere_scene_spot(gpu_ctx):
+    """BASELINE configs[4] shape: 1000x1000 cells (~1 M spheres, ~2 M nodes), 1920x1080; spot-checked pixels at 8 spp."""
+    nx, ny, ns, half = 1920, 1080, 8, 500
+    hs = rrt_amd.HostScene(rrt_amd.SCENE_RANDOM_SPHERES, nx, ny, seed=0, half=half)
+    assert hs.n_spheres > 990000
+    gpu_ctx.upload_host_scene(hs)
+    rgb, acc, st = gpu_ctx.render(rrt_amd.Context.params(nx, ny, ns, seed=0))
+    sp, mt, nd, cam = hs.export()
+    osc = OracleScene.from_arrays(sp, np.arange(sp.shape[0], dtype=np.uint32), mt, nd, cam.as_array())
+    idx = np.random.default_rng(1).choice(nx * ny, 48, replace=False).astype(np.uint32)
+    acc_o, rgb_o, _ = osc.render_pixels(nx, ny, ns, 0, idx)
+    assert np.array_equal(bits(acc.reshape(-1, 3)[idx]), bits(acc_o))
+    assert np.array_equal(rgb.reshape(-1, 3)[idx], rgb_o)
+    assert st["paths"] == nx * ny * ns
