@@ -192,19 +192,22 @@ struct LdsStore {
     uint32_t root16;
     DEV LdsStore(const uint4 *p, uint32_t r) : v4(p), root16(r) {}
     DEV uint32_t root() const { return root16; }
+    // byte offset of node i without an integer multiply: 48 = 32 + 16, 64 = 1 << 6
+    DEV static uint32_t node_bytes(uint32_t i) { return MOVING ? (i << 6) : ((i << 5) + (i << 4)); }
     DEV bool uniform_times() const { return MOVING; }  // the compact copy exists only for scenes with one shutter interval
     DEV void inner(uint32_t cur, uint32_t oct, f32x2 &bx, f32x2 &by, f32x2 &bz, uint32_t &near_ref, uint32_t &exit_ref) const {
-        const uint32_t off = __umul24(cur, W / 4u);  // cur is an inner-node index here, far below 2^24
-        const uint4 n0 = v4[off];
-        const uint4 n1 = v4[off + 1u];
-        exit_ref = reinterpret_cast<const uint16_t *>(v4)[off * 8u + 16u + oct];
+        const char *node = reinterpret_cast<const char *>(v4) + node_bytes(cur);
+        const uint4 n0 = *reinterpret_cast<const uint4 *>(node);
+        const uint4 n1 = *reinterpret_cast<const uint4 *>(node + 16);
+        exit_ref = *reinterpret_cast<const uint16_t *>(node + 32u + 2u * oct);
         bx = f32x2{u2f(n0.x), u2f(n0.y)}; by = f32x2{u2f(n0.z), u2f(n0.w)}; bz = f32x2{u2f(n1.x), u2f(n1.y)};
         near_ref = ((oct >> n1.w) & 1u) ? (n1.z >> 16) : (n1.z & 0xFFFFu);
     }
     DEV void leaf(uint32_t cur, const RayCtx &r, V3 &c, float &rr, uint32_t &handle, uint32_t &exit_ref) const {
         const uint32_t idx = cur & (kRef16LeafBit - 1u);
-        const uint4 n0 = v4[idx * (W / 4u)];
-        exit_ref = reinterpret_cast<const uint16_t *>(v4)[idx * (W * 2u) + 16u + r.oct];
+        const char *node = reinterpret_cast<const char *>(v4) + node_bytes(idx);
+        const uint4 n0 = *reinterpret_cast<const uint4 *>(node);
+        exit_ref = *reinterpret_cast<const uint16_t *>(node + 32u + 2u * r.oct);
         c = mk(u2f(n0.x), u2f(n0.y), u2f(n0.z));
         rr = u2f(n0.w);
         handle = idx;
@@ -268,7 +271,7 @@ DEV uint64_t wave_sum_u64(uint64_t v) {
 }
 
 // One wave's share of an extend launch.  The wave's live-slot list is a pool of rays: whenever lanes finish their ray
-// they are given the next rays of the list, which a look-ahead buffer has already brought in from HBM.  Inside a ray the walk alternates "descend through inner nodes" and "test one
+// they are given the next rays of the list (the list itself is read up front, one column per lane).  Inside a ray the walk alternates "descend through inner nodes" and "test one
 // sphere" (the latter once `leaf_min` lanes wait for it), so that lanes run the same kind of step together.  Finished
 // lanes wait until at least `retire_min` of them can be retired and restarted in one go (or nothing else is left).
 template <class Store, bool MOVING, bool COUNT>
@@ -286,17 +289,12 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
     const uint32_t q1 = lane + 64u < count ? P.queue[base + lane + 64u] : 0u;
     const uint32_t q2 = lane + 128u < count ? P.queue[base + lane + 128u] : 0u;
     const uint32_t q3 = lane + 192u < count ? P.queue[base + lane + 192u] : 0u;
-    // Look-ahead buffer: lane l always holds the not yet started ray of list position l + 64*bj (its own column, so
-    // the loads need no address from another load).  Rays are handed out in list order to whichever lanes retire, by
-    // a cross-lane read of the buffer; a consumed buffer entry is refilled at once and arrives while the walk goes on.
-    uint32_t bj = 0, bslot = q0, slot = 0;
-    bool bvalid = lane < count, has = false;
-    float4 bA = make_float4(0, 0, 0, 0), bB = bA, bC = bA;
-    if (bvalid) { bA = P.rayA[bslot]; bB = P.rayB[bslot]; bC = P.rayC[bslot]; }
+    uint32_t slot = 0;
+    bool has = false;
     uint32_t head = 0;  // first list position not handed out yet (wave-uniform)
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     RayCtx r;
-    ray_load(r, bA, bB, bC, 0.001f, __FLT_MAX__, S, false);
+    ray_load(r, make_float4(0, 0, 0, 0), make_float4(1, 1, 1, 0), make_float4(1, 1, 1, 3), 0.001f, __FLT_MAX__, S, false);
     uint32_t cur = Store::kEnd;
     for (;;) {
         const bool idle = cur == Store::kEnd;
@@ -304,32 +302,29 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
         const uint64_t ready = __ballot(idle && (has || head < count));
         if (~idle_m == 0ull || (uint32_t)__popcll(ready) >= retire_min) {
             if (COUNT) { d_retires++; d_retire_lanes += (uint32_t)__popcll(ready); }
+            // every idle lane takes the next ray of the list, in lane order; list entry p sits in lane p % 64, register p / 64
+            const uint32_t pos = head + (uint32_t)__popcll(idle_m & lt_mask);
+            const uint32_t col = pos >> 6;
+            const uint32_t q_sel = col == 0u ? q0 : (col == 1u ? q1 : (col == 2u ? q2 : q3));
+            (void)q_sel;
+            const int src = (int)(pos & 63u);
+            const uint32_t s0 = (uint32_t)__shfl((int)q0, src, 64), s1 = (uint32_t)__shfl((int)q1, src, 64);
+            const uint32_t s2 = (uint32_t)__shfl((int)q2, src, 64), s3 = (uint32_t)__shfl((int)q3, src, 64);
+            const uint32_t n_slot = col == 0u ? s0 : (col == 1u ? s1 : (col == 2u ? s2 : s3));
+            const bool take = idle && pos < count;
+            float4 nA = make_float4(0, 0, 0, 0), nB = nA, nC = nA;
+            if (take) { nA = P.rayA[n_slot]; nB = P.rayB[n_slot]; nC = P.rayC[n_slot]; }
             if (idle && has) {
                 P.hit[slot] = make_uint2(f2u(r.tmax), r.best == kPrimNone ? kPrimNone : st.prim_of(r.best));
                 has = false;
             }
-            // every idle lane takes the next ray of the list, in lane order
-            const uint32_t pos = head + (uint32_t)__popcll(idle_m & lt_mask);
-            const int src = (int)(pos & 63u);
-            const uint32_t n_slot = (uint32_t)__shfl((int)bslot, src, 64);
-            float4 nA, nB, nC;
-            nA.x = __shfl(bA.x, src, 64); nA.y = __shfl(bA.y, src, 64); nA.z = __shfl(bA.z, src, 64); nA.w = __shfl(bA.w, src, 64);
-            nB.x = __shfl(bB.x, src, 64); nB.y = __shfl(bB.y, src, 64); nB.z = __shfl(bB.z, src, 64); nB.w = __shfl(bB.w, src, 64);
-            nC.x = __shfl(bC.x, src, 64); nC.y = __shfl(bC.y, src, 64); nC.z = __shfl(bC.z, src, 64); nC.w = __shfl(bC.w, src, 64);
-            if (idle && pos < count) {
+            if (take) {
                 slot = n_slot;
                 ray_load(r, nA, nB, nC, 0.001f, __FLT_MAX__, S, uniform_times);  // lib.rs:57
                 cur = st.root();
                 has = true;
             }
-            const uint32_t taken = min((uint32_t)__popcll(idle_m), count - head);
-            if (bvalid && ((lane - head) & 63u) < taken) {  // this lane's buffer entry was handed out: fetch the column's next
-                bj++;
-                bslot = bj == 1u ? q1 : (bj == 2u ? q2 : q3);
-                bvalid = bj < 4u && lane + 64u * bj < count;
-                if (bvalid) { bA = P.rayA[bslot]; bB = P.rayB[bslot]; bC = P.rayC[bslot]; }
-            }
-            head += taken;
+            head += min((uint32_t)__popcll(idle_m), count - head);
             if (__ballot(has) == 0ull) break;
         }
         // descend until no lane is at an inner node, or enough lanes wait at a sphere for a test to be worth a pass
