@@ -117,38 +117,42 @@ DEV void generate_path(const BatchDev &Bt, const CameraDev &C, uint32_t p, float
 // A node store hands out the words of a node; two exist: the 64-byte nodes in HBM (any scene) and the compact copy in
 // LDS (small scenes).  References order as inner < kEnd < leaf, so `cur < kEnd` means "inner node".
 struct RayCtx {
-    V3 o, d, inv;
+    f32x2 ox, oy, oz;  // per axis {origin, 1 / direction}: both ray operands of the slab arithmetic in one aligned register pair
+    V3 d;
     float a;      // d.d (sphere.rs:71), the same for every sphere
     float time, f_ray;
     float tmin, tmax;
     uint32_t oct;   // bit k set: 1/d[k] < 0 (acceleration.rs:230-231)
+    uint32_t sgn;   // the same three bits at positions 4, 12 and 20: (sgn >> 8 * axis) & 0x1F is 16 if the ray is negative along axis
     uint32_t best;  // store-specific handle of the closest leaf so far
 };
 
-DEV void ray_load(RayCtx &r, float4 A, float4 B, float4 C, float tmin, float tmax, const SceneDev &S, bool uniform_times) {
-    r.o = mk(A.x, A.y, A.z);
-    r.d = mk(B.x, B.y, B.z);
-    r.time = A.w;
-    r.inv = mk(C.x, C.y, C.z);
-    r.oct = (r.inv.x < 0.0f ? 1u : 0u) | (r.inv.y < 0.0f ? 2u : 0u) | (r.inv.z < 0.0f ? 4u : 0u);  // acceleration.rs:230-231
-    r.a = C.w;
-    r.f_ray = uniform_times ? (r.time - S.u_time0) / S.u_dt : 0.0f;
+DEV V3 origin(const RayCtx &r) { return mk(r.ox.x, r.oy.x, r.oz.x); }
+
+DEV void ray_finish(RayCtx &r, float tmin, float tmax, const SceneDev &S, bool uniform_times) {
+    const uint32_t nx = r.ox.y < 0.0f ? 1u : 0u, ny = r.oy.y < 0.0f ? 1u : 0u, nz = r.oz.y < 0.0f ? 1u : 0u;  // acceleration.rs:230-231
+    r.oct = nx | (ny << 1) | (nz << 2);
+    r.sgn = (nx << 4) | (ny << 12) | (nz << 20);
+    r.f_ray = uniform_times ? (r.time - S.u_time0) / S.u_dt : 0.0f;  // center_at's factor when every moving sphere shares its shutter interval
     r.tmin = tmin;
     r.tmax = tmax;
     r.best = kPrimNone;
 }
 
-DEV void ray_setup(RayCtx &r, float4 A, float4 B, float tmin, float tmax, const SceneDev &S, bool uniform_times) {
-    r.o = mk(A.x, A.y, A.z);
+DEV void ray_load(RayCtx &r, float4 A, float4 B, float4 C, float tmin, float tmax, const SceneDev &S, bool uniform_times) {
+    r.ox = f32x2{A.x, C.x}; r.oy = f32x2{A.y, C.y}; r.oz = f32x2{A.z, C.z};
     r.d = mk(B.x, B.y, B.z);
     r.time = A.w;
-    r.inv = mk(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);  // types.rs:21-23
-    r.oct = (r.inv.x < 0.0f ? 1u : 0u) | (r.inv.y < 0.0f ? 2u : 0u) | (r.inv.z < 0.0f ? 4u : 0u);
+    r.a = C.w;
+    ray_finish(r, tmin, tmax, S, uniform_times);
+}
+
+DEV void ray_setup(RayCtx &r, float4 A, float4 B, float tmin, float tmax, const SceneDev &S, bool uniform_times) {
+    r.d = mk(B.x, B.y, B.z);
+    r.ox = f32x2{A.x, 1.0f / r.d.x}; r.oy = f32x2{A.y, 1.0f / r.d.y}; r.oz = f32x2{A.z, 1.0f / r.d.z};  // types.rs:21-23
+    r.time = A.w;
     r.a = dot3(r.d, r.d);
-    r.f_ray = uniform_times ? (r.time - S.u_time0) / S.u_dt : 0.0f;  // center_at's factor when every moving sphere shares its shutter interval
-    r.tmin = tmin;
-    r.tmax = tmax;
-    r.best = kPrimNone;
+    ray_finish(r, tmin, tmax, S, uniform_times);
 }
 
 template <bool MOVING>
@@ -158,7 +162,7 @@ struct HbmStore {
     DEV explicit HbmStore(const SceneDev &s) : S(s) {}
     DEV uint32_t root() const { return S.root_ref; }
     DEV bool uniform_times() const { return MOVING && (S.flags & kSceneUniformTimes); }
-    DEV void inner(uint32_t cur, uint32_t oct, f32x2 &bx, f32x2 &by, f32x2 &bz, uint32_t &near_ref, uint32_t &exit_ref) const {
+    DEV void inner(uint32_t cur, uint32_t oct, uint32_t, f32x2 &bx, f32x2 &by, f32x2 &bz, uint32_t &near_ref, uint32_t &exit_ref) const {
         const uint32_t idx = cur & kRefIndexMask;
         const uint4 n0 = S.nodes[idx * 4u];
         const uint4 n1 = S.nodes[idx * 4u + 1u];
@@ -192,63 +196,78 @@ struct LdsStore {
     uint32_t root16;
     DEV LdsStore(const uint4 *p, uint32_t r) : v4(p), root16(r) {}
     DEV uint32_t root() const { return root16; }
-    // byte offset of node i without an integer multiply: 48 = 32 + 16, 64 = 1 << 6
-    DEV static uint32_t node_bytes(uint32_t i) { return MOVING ? (i << 6) : ((i << 5) + (i << 4)); }
     DEV bool uniform_times() const { return MOVING; }  // the compact copy exists only for scenes with one shutter interval
-    DEV void inner(uint32_t cur, uint32_t oct, f32x2 &bx, f32x2 &by, f32x2 &bz, uint32_t &near_ref, uint32_t &exit_ref) const {
-        const char *node = reinterpret_cast<const char *>(v4) + node_bytes(cur);
+    // a reference is the node's offset in 16-byte units (bit 15: leaf)
+    DEV const char *node_at(uint32_t off16) const { return reinterpret_cast<const char *>(v4) + (off16 << 4); }
+    DEV void inner(uint32_t cur, uint32_t oct, uint32_t sgn, f32x2 &bx, f32x2 &by, f32x2 &bz, uint32_t &near_ref, uint32_t &exit_ref) const {
+        const char *node = node_at(cur);
         const uint4 n0 = *reinterpret_cast<const uint4 *>(node);
         const uint4 n1 = *reinterpret_cast<const uint4 *>(node + 16);
         exit_ref = *reinterpret_cast<const uint16_t *>(node + 32u + 2u * oct);
         bx = f32x2{u2f(n0.x), u2f(n0.y)}; by = f32x2{u2f(n0.z), u2f(n0.w)}; bz = f32x2{u2f(n1.x), u2f(n1.y)};
-        near_ref = ((oct >> n1.w) & 1u) ? (n1.z >> 16) : (n1.z & 0xFFFFu);
+        near_ref = (n1.z >> ((sgn >> n1.w) & 0x1Fu)) & 0xFFFFu;  // left in the low half, right in the high half; n1.w = 8 * axis
     }
     DEV void leaf(uint32_t cur, const RayCtx &r, V3 &c, float &rr, uint32_t &handle, uint32_t &exit_ref) const {
-        const uint32_t idx = cur & (kRef16LeafBit - 1u);
-        const char *node = reinterpret_cast<const char *>(v4) + node_bytes(idx);
+        const uint32_t off16 = cur & (kRef16LeafBit - 1u);
+        const char *node = node_at(off16);
         const uint4 n0 = *reinterpret_cast<const uint4 *>(node);
         exit_ref = *reinterpret_cast<const uint16_t *>(node + 32u + 2u * r.oct);
         c = mk(u2f(n0.x), u2f(n0.y), u2f(n0.z));
         rr = u2f(n0.w);
-        handle = idx;
+        handle = off16;
         if (MOVING) {
-            const uint4 m = v4[idx * (W / 4u) + 3u];  // centre1 - centre0, zero words for a sphere at rest
-            if (reinterpret_cast<const uint32_t *>(v4)[idx * W + 5u] & 1u) c = add(c, scale(r.f_ray, mk(u2f(m.x), u2f(m.y), u2f(m.z))));
+            const uint4 m = *reinterpret_cast<const uint4 *>(node + 48);  // centre1 - centre0, zero words for a sphere at rest
+            if (*reinterpret_cast<const uint32_t *>(node + 20) & 1u) c = add(c, scale(r.f_ray, mk(u2f(m.x), u2f(m.y), u2f(m.z))));
         }
     }
-    DEV uint32_t prim_of(uint32_t handle) const { return reinterpret_cast<const uint32_t *>(v4)[handle * W + 4u]; }
+    DEV uint32_t prim_of(uint32_t handle) const { return *reinterpret_cast<const uint32_t *>(node_at(handle) + 16); }
 };
 
 // Aabb::intersect (acceleration.rs:60-84) against the current t_max, then the step of acceleration.rs:250-267.
 // Node boxes are stored as (min, max) pairs per axis, so both planes of an axis go through one packed subtract and
 // one packed multiply; which of the two results is "near" is chosen afterwards by the sign of 1/d, which selects
 // the same operands the reference's blend selects before its arithmetic.
+// (box - origin) * (1 / direction) for both planes of one axis.  `oi` is {origin, 1 / direction}: the subtract reads its
+// low half for both results and the multiply its high half, so the ray needs no duplicated operands in registers.
+DEV f32x2 slab_pair(f32x2 box, f32x2 oi) {
+    f32x2 diff, t;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(diff) : "v"(box), "v"(oi));
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(t) : "v"(diff), "v"(oi));
+    return t;
+}
+
 template <class Store>
 DEV uint32_t visit_inner(const Store &st, uint32_t cur, const RayCtx &r) {
     f32x2 bx, by, bz;
     uint32_t near_ref, exit_ref;
-    st.inner(cur, r.oct, bx, by, bz, near_ref, exit_ref);
-    const f32x2 tx = (bx - f32x2{r.o.x, r.o.x}) * f32x2{r.inv.x, r.inv.x};
-    const f32x2 ty = (by - f32x2{r.o.y, r.o.y}) * f32x2{r.inv.y, r.inv.y};
-    const f32x2 tz = (bz - f32x2{r.o.z, r.o.z}) * f32x2{r.inv.z, r.inv.z};
+    st.inner(cur, r.oct, r.sgn, bx, by, bz, near_ref, exit_ref);
+    const f32x2 tx = slab_pair(bx, r.ox), ty = slab_pair(by, r.oy), tz = slab_pair(bz, r.oz);
     const bool ngx = r.oct & 1u, ngy = r.oct & 2u, ngz = r.oct & 4u;
     const float tnx = ngx ? tx.y : tx.x, tny = ngy ? ty.y : ty.x, tnz = ngz ? tz.y : tz.x;
-    const float tfx = (ngx ? tx.x : tx.y) * RRT_FAR_SCALE;
-    const float tfy = (ngy ? ty.x : ty.y) * RRT_FAR_SCALE;
-    const float tfz = (ngz ? tz.x : tz.y) * RRT_FAR_SCALE;
-    const float t0 = fmaxf(fmaxf(fmaxf(tnx, tny), tnz), r.tmin);
-    const float t1 = fminf(fminf(fminf(tfx, tfy), tfz), r.tmax);
+    const float tfx = ngx ? tx.x : tx.y, tfy = ngy ? ty.x : ty.y, tfz = ngz ? tz.x : tz.y;
+    // each far value is scaled by 1 + 2*gamma(3) (acceleration.rs:60-84); rounding x -> x * k is monotonic, so scaling
+    // the smallest of the three gives bit for bit the smallest of the three scaled values.  The min/max chains are
+    // spelled as instructions because the compiler cannot know that the packed results above are already canonical
+    // and would re-canonicalise each of them first.
+    float n3, t0, f3, t1;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(n3) : "v"(tnx), "v"(tny), "v"(tnz));
+    asm("v_max_f32 %0, %1, %2" : "=v"(t0) : "v"(n3), "v"(r.tmin));
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(f3) : "v"(tfx), "v"(tfy), "v"(tfz));
+    const float f3s = f3 * RRT_FAR_SCALE;
+    asm("v_min_f32 %0, %1, %2" : "=v"(t1) : "v"(f3s), "v"(r.tmax));
     return (t0 <= t1) ? near_ref : exit_ref;  // the far child is the near child's exit link
 }
 
-// Sphere::hit (sphere.rs:68-85); the Hit record itself is rebuilt in shade, for the final hit only
+// Sphere::hit (sphere.rs:68-85); the Hit record itself is rebuilt in shade, for the final hit only.  (Deferring the
+// square root and divisions until many lanes need them was tried: lanes that wait for roots cost the descent passes as
+// many idle lanes as the batched root passes save.)
 template <class Store>
 DEV uint32_t visit_leaf(const Store &st, uint32_t cur, RayCtx &r) {
     V3 c;
     float rr;
     uint32_t handle, exit_ref;
     st.leaf(cur, r, c, rr, handle, exit_ref);
-    const V3 oc = sub(r.o, c);
+    const V3 oc = sub(origin(r), c);
     const float half_b = dot3(oc, r.d);
     const float cc = dot3(oc, oc) - rr;
     const float disc = (half_b * half_b) - (r.a * cc);

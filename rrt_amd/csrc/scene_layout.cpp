@@ -140,14 +140,15 @@ int build_scene_layout(const rrt_sphere_soa *sp, const rrt_material_soa *mt, con
         }
     }
 
-    // ---- compact copy for LDS residency: 16-bit references, 48 or 64 bytes per node ----
+    // ---- compact copy for LDS residency: 48 or 64 bytes per node; a 16-bit reference is the node's offset in 16-byte
+    //      units (so a shift makes the LDS address), bit 15 marks a leaf ----
     const bool moving = (out.flags & kSceneHasMoving) != 0;
     const uint32_t sw = moving ? kSmallWordsMoving : kSmallWordsStatic;
     const bool times_ok = !moving || (out.flags & kSceneUniformTimes) != 0;
-    if (times_ok && n_nodes < kRef16End && static_cast<size_t>(n_nodes) * sw * 4 <= kSmallLdsBudget) {
+    if (times_ok && static_cast<size_t>(n_nodes) * sw * 4 <= kSmallLdsBudget) {
         auto ref16 = [&](uint32_t r) -> uint32_t {
             if (r == kRefEnd) return kRef16End;
-            return (r & kRefIndexMask) | ((r & kRefLeafBit) ? kRef16LeafBit : 0u);
+            return (r & kRefIndexMask) * (sw / 4u) | ((r & kRefLeafBit) ? kRef16LeafBit : 0u);
         };
         out.small_words = sw;
         out.small_nodes.assign(static_cast<size_t>(n_nodes) * sw, 0u);
@@ -157,7 +158,7 @@ int build_scene_layout(const rrt_sphere_soa *sp, const rrt_material_soa *mt, con
             for (int k = 0; k < 6; k++) s[k] = w[k];
             if (!is_leaf(nodes[i])) {
                 s[6] = ref16(w[7]) | (ref16(w[6] & (kRefLeafBit | kRefIndexMask)) << 16);
-                s[7] = (w[6] >> RRT_NODE_AXIS_SHIFT) & 3u;
+                s[7] = ((w[6] >> RRT_NODE_AXIS_SHIFT) & 3u) * 8u;  // bit offset of the axis' field in the ray's sign word
             } else if (moving && (w[5] & 1u)) {
                 const Float4 &m = out.motion[w[4]];
                 s[12] = f2u(m.x); s[13] = f2u(m.y); s[14] = f2u(m.z);

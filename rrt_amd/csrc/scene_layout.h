@@ -20,7 +20,8 @@ constexpr uint32_t kRefEnd = 0x7FFFFFFFu;       // "nothing left to visit"
 constexpr uint32_t kRefIndexMask = 0x1FFFFFFFu; // node index inside a reference
 constexpr uint32_t kNodeWords = 16;             // 64 bytes
 
-// Compact layout for scenes small enough to live in a workgroup's LDS: 16-bit references.
+// Compact layout for scenes small enough to live in a workgroup's LDS.  A 16-bit reference is the node's offset in
+// 16-byte units (at most 4095 inside the 64 KB budget) with bit 15 set for a leaf.
 constexpr uint32_t kRef16LeafBit = 0x8000u;
 constexpr uint32_t kRef16End = 0x7FFFu;
 constexpr uint32_t kSmallWordsStatic = 12;   // 48 bytes per node
@@ -49,7 +50,7 @@ struct SceneLayout {
 
     // Compact node words (empty when the scene does not qualify).  [0..5] inner: (min, max) per axis; leaf: centre,
     // radius^2, sphere index, moving flag.  [6] inner: left ref16 | right
-    // ref16 << 16.  [7] inner: axis.  [8..11] eight 16-bit exit links.  [12..14] (moving scenes) centre1 - centre0.
+    // ref16 << 16.  [7] inner: 8 * axis.  [8..11] eight 16-bit exit links.  [12..14] (moving scenes) centre1 - centre0.
     std::vector<uint32_t> small_nodes;
     uint32_t small_words = 0;
     uint32_t small_root = kRef16End;
