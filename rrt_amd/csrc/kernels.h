@@ -48,7 +48,7 @@ struct PathState {
     float4 *rayC;      // 1/direction xyz (types.rs:21-23), direction.direction (sphere.rs:71): per-ray constants of the walk
     uint4 *rng;        // Xoshiro128Plus state
     uint32_t *depth;   // scatters so far (low 16 bits) | trail entries written (high 16 bits)
-    uint2 *hit;        // extend -> shade: {t bits, sphere index or kPrimNone}
+    uint2 *hit;        // extend -> shade: {t bits, sphere index | material kind << 30, or kPrimNone}
     uint4 *recent;     // the four newest spheres the path scattered off (dielectrics excepted), newest first
     uint32_t *trail;   // [slot / 64][level][slot % 64] the older ones; both feed the back-to-front product of lib.rs:62
     uint32_t *queue;

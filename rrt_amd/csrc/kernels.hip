@@ -33,6 +33,8 @@ DEV V3 neg(V3 a) { return mk(-a.x, -a.y, -a.z); }
 DEV float dot3(V3 a, V3 b) { return __builtin_fmaf(a.x, b.x, __builtin_fmaf(a.y, b.y, __builtin_fmaf(a.z, b.z, 0.0f))); }
 // ultraviolet normalized(): reciprocal of the magnitude, then one multiply per lane
 DEV V3 normalized(V3 a) { const float r = 1.0f / sqrtf(dot3(a, a)); return mk(a.x * r, a.y * r, a.z * r); }
+// the multiply half of normalized(): a * (1 / |a|), each component times the reciprocal
+DEV V3 scale_r(V3 a, float r) { return mk(a.x * r, a.y * r, a.z * r); }
 // ultraviolet reflected(): self - (2 * self.dot(n)) * n
 DEV V3 reflected(V3 i, V3 n) { const float k = 2.0f * dot3(i, n); return sub(i, scale(k, n)); }
 
@@ -69,14 +71,6 @@ DEV void seed_from_u64(Rng &g, uint64_t seed) {
         g.s0 = (uint32_t)z1; g.s1 = (uint32_t)(z1 >> 32); g.s2 = (uint32_t)z2; g.s3 = (uint32_t)(z2 >> 32);
         if ((g.s0 | g.s1 | g.s2 | g.s3) != 0u) return;
         seed = 0;  // an all-zero state is replaced by seed_from_u64(0)
-    }
-}
-
-DEV V3 in_unit_sphere(Rng &g) {  // rng.rs:32-40
-    for (;;) {
-        const float x = sample_pm1(g), y = sample_pm1(g), z = sample_pm1(g);
-        const V3 v = mk(x, y, z);
-        if (dot3(v, v) < 1.0f) return v;
     }
 }
 
@@ -178,10 +172,11 @@ struct HbmStore {
         exit_ref = reinterpret_cast<const uint32_t *>(S.nodes)[idx * kNodeWords + 8u + r.oct];
         c = mk(u2f(n0.x), u2f(n0.y), u2f(n0.z));
         rr = u2f(n0.w);
-        handle = n1.x;
+        handle = n1.x;  // sphere index | material kind << 30
         if (MOVING && (n1.y & 1u)) {  // center_at (sphere.rs:61-64)
-            const float4 m = S.motion[n1.x];
-            const float f = (S.flags & kSceneUniformTimes) ? r.f_ray : (r.time - m.w) / S.motion_dt[n1.x];
+            const uint32_t prim = n1.x & kLeafPrimMask;
+            const float4 m = S.motion[prim];
+            const float f = (S.flags & kSceneUniformTimes) ? r.f_ray : (r.time - m.w) / S.motion_dt[prim];
             c = add(c, scale(f, mk(m.x, m.y, m.z)));
         }
     }
@@ -369,8 +364,10 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
         const uint64_t si = wave_sum_u64(n_inner), sl = wave_sum_u64(n_leaf);
         if (lane == 0) {
             stt[ST_INNER] += si; stt[ST_LEAF] += sl;
+#ifndef RRT_SHADE_TIMING
             stt[10] += d_desc_iters; stt[11] += d_desc_lanes; stt[12] += d_leaf_iters; stt[13] += d_leaf_lanes; stt[14] += d_retires;
             stt[15] += d_retire_lanes;
+#endif
         }
     }
     if (lane == 0) stt[ST_RAYS] += count;
@@ -411,8 +408,10 @@ DEV float reflectance(float cosine, float ref_idx) {  // materials.rs:65-69
 
 // Path ids are dealt in groups of 64 consecutive ids, group g belonging to cursor shard g % n_shards; a wave draws
 // from shard wave % n_shards.  `n` is the wave's running count of claims from its shard.
+DEV uint64_t path_of_claim(const BatchDev &Bt, uint32_t shard, uint32_t n) { return ((uint64_t)(n >> 6) * Bt.n_shards + shard) * 64ull + (n & 63u); }
+
 DEV bool start_path(const PathState &P, const BatchDev &Bt, const CameraDev &C, uint32_t shard, uint32_t n, uint32_t slot) {
-    const uint64_t p64 = ((uint64_t)(n >> 6) * Bt.n_shards + shard) * 64ull + (n & 63u);
+    const uint64_t p64 = path_of_claim(Bt, shard, n);
     if (p64 >= (uint64_t)Bt.n_paths) return false;
     float4 A, B, K;
     Rng g;
@@ -460,43 +459,69 @@ DEV size_t trail_index(const PathState &P, uint32_t level, uint32_t slot) {
     return ((size_t)(slot >> 6) * P.trail_levels + level) * 64u + (slot & 63u);
 }
 
-// What shade reads of one path slot
+// ---- shade ----
+//
+// A wave shades the (up to) 256 live slots of its list, four tiles of 64, in these steps:
+//   1. classify every slot by what happened to its ray (the extend kernel packs the material kind of the sphere into
+//      the hit record), park the generator states in LDS, and claim path ids for every path that is known to end
+//      (sky, depth limit) with one cursor update;
+//   2. run the in-unit-sphere rejection loop of every Lambertian and metal slot (rng.rs:32-40).  A lane owns the slots
+//      of its column of the list and moves on to its next slot as soon as a sample is accepted, so one lane's
+//      rejections do not hold up a whole tile.  What waits in LDS is the generator state just before the accepted
+//      draw: step 3 repeats that one draw;
+//   3. per tile: hit record, scatter, sky, trail bookkeeping; an ended path's slot starts its next path right there,
+//      so that each array of the path state gets one store covering (nearly) all 64 neighbouring slots;
+//   4. the few slots whose path was absorbed by a metal sphere (materials.rs:57-60) are refilled, compacted;
+//   5. the live-slot list is rewritten in slot order (ballot + prefix popcount), so that the 64 lanes of a tile keep
+//      touching neighbouring slots.
+// (Sorting the list by class so that tiles run one material's code was tried: the scattered 16-byte stores that follow
+// cost more HBM traffic than the saved instructions are worth.)
+enum : uint32_t { CL_LAMB = 0, CL_METAL = 1, CL_DIEL = 2, CL_SKY = 3, CL_CUT = 4, CL_NONE = 5 };
+static_assert(RRT_MAT_LAMBERTIAN == CL_LAMB && RRT_MAT_METAL == CL_METAL && RRT_MAT_DIELECTRIC == CL_DIEL, "material kinds double as classes");
+
+// LDS words per wave: one 16-byte entry per list position
+constexpr uint32_t kShadeLdsWords = kWaveSlots * 4u;
+constexpr uint32_t kShadeWavesPerBlock = kBlockThreads / 64u;
+
+// What step 3 reads of one path slot
 struct SlotIn {
     float4 A, B;
     uint2 h;
     uint32_t depth;
-    uint4 rng;
     uint4 recent;  // the four most recent trail entries, newest first
 };
 DEV void load_slot(const PathState &P, bool active, uint32_t slot, SlotIn &in) {
-    if (active) {
-        in.A = P.rayA[slot]; in.B = P.rayB[slot]; in.h = P.hit[slot]; in.depth = P.depth[slot]; in.rng = P.rng[slot];
-        in.recent = P.recent[slot];
-    }
+    if (active) { in.A = P.rayA[slot]; in.B = P.rayB[slot]; in.h = P.hit[slot]; in.depth = P.depth[slot]; in.recent = P.recent[slot]; }
 }
 
-// Shades one tile (64 live slots) of the wave.  Returns per lane whether the path goes on (`alive`) or ended (`need`:
-// its slot wants a new path).
-template <bool MOVING, bool COUNT>
-DEV void shade_slot(const SceneDev &S, const PathState &P, const BatchDev &Bt, uint32_t slot, const SlotIn &in, bool &alive, bool &need,
-                    uint32_t &ev) {
+// Step 3 for one lane.  `gw` is the slot's LDS entry: the generator state (before the accepted draw, for Lambertian and
+// metal).  `next_n` is the claim number of the path that takes over the slot if this one ends here.
+template <bool MOVING>
+DEV void shade_slot(const SceneDev &S, const PathState &P, const BatchDev &Bt, const CameraDev &C, uint32_t cls, uint32_t slot,
+                    const SlotIn &in, uint4 gw, uint32_t shard, uint32_t next_n, bool &alive, bool &absorbed, bool &started) {
     const float4 A = in.A, B = in.B;
-    const uint2 h = in.h;
     const uint32_t depth = in.depth & 0xFFFFu;       // scatters so far
     const uint32_t trail_len = in.depth >> 16;       // of which recorded on the trail
     const uint32_t pid = f2u(B.w);
     const V3 o = mk(A.x, A.y, A.z), d = mk(B.x, B.y, B.z);
     const float time = A.w;
     float rx = 0.0f, ry = 0.0f, rz = 0.0f;  // radiance of a finished path
-    if (h.y == kPrimNone) {
+    // what the slot holds afterwards
+    float4 oA = A, oB = B, oC = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    Rng g;
+    g.s0 = gw.x; g.s1 = gw.y; g.s2 = gw.z; g.s3 = gw.w;
+    uint32_t o_depth = 0u;
+    bool ended = false;
+    // 1 / |d|, shared by everything that needs the unit direction: the sky (lib.rs:67), metal (materials.rs:47) and glass (materials.rs:83)
+    float inv_len = 0.0f;
+    if (cls == CL_METAL || cls == CL_DIEL || cls == CL_SKY) inv_len = 1.0f / sqrtf(dot3(d, d));
+    if (cls == CL_SKY) {
         // sky (lib.rs:66-70), then the product of attenuations innermost first (lib.rs:62).  The spheres scattered off
         // on the way are read back from the trail, eight levels per round so that a long path costs few memory round
         // trips.  Dielectric hits are not on the trail: their attenuation is (1,1,1) and x * 1 is x.
-        if (COUNT) ev = ST_SKY;
         const uint32_t *tr = P.trail + trail_index(P, 0u, slot);
         const size_t ns = 64u;  // level stride inside a 64-slot group
-        const float r = 1.0f / sqrtf(dot3(d, d));
-        const float uy = d.y * r;
+        const float uy = d.y * inv_len;
         const float t = 0.5f * (uy + 1.0f);
         const float w = 1.0f - t;
         rx = w + t * 0.5f;  // white.lerp(sky_blue, t) = white*(1-t) + sky_blue*t
@@ -504,10 +529,10 @@ DEV void shade_slot(const SceneDev &S, const PathState &P, const BatchDev &Bt, u
         rz = w + t * 1.0f;
         // the newest four levels travel with the path state; older ones are in the trail planes
         {
-            const uint32_t w[4] = {in.recent.x, in.recent.y, in.recent.z, in.recent.w};
+            const uint32_t w4[4] = {in.recent.x, in.recent.y, in.recent.z, in.recent.w};
             float4 at[4];
 #pragma unroll
-            for (uint32_t k = 0; k < 4u; k++) at[k] = S.prim_att[k < trail_len ? w[k] : 0u];
+            for (uint32_t k = 0; k < 4u; k++) at[k] = S.prim_att[k < trail_len ? w4[k] : 0u];
 #pragma unroll
             for (uint32_t k = 0; k < 4u; k++)
                 if (k < trail_len) { rx = at[k].x * rx; ry = at[k].y * ry; rz = at[k].z * rz; }
@@ -529,21 +554,20 @@ DEV void shade_slot(const SceneDev &S, const PathState &P, const BatchDev &Bt, u
             }
             j -= m;
         }
-        need = true;
-    } else if (depth >= Bt.max_depth) {  // lib.rs:58-60
-        if (COUNT) ev = ST_DEPTHCUT;
-        need = true;
-    } else {
-        const uint32_t prim = h.y;
-        const float t = u2f(h.x);
+        ended = true;
+    } else if (cls == CL_CUT) {  // lib.rs:58-60
+        ended = true;
+    } else if (cls != CL_NONE) {
+        const uint32_t prim = in.h.y & kLeafPrimMask;
+        const float t = u2f(in.h.x);
         const float4 sp = S.sph[prim];
-        const uint32_t info = S.sph_info[prim];
-        const float4 mt = S.pmat[prim];
         V3 c = mk(sp.x, sp.y, sp.z);
-        if (MOVING && (info & kInfoMovingBit)) {  // sphere.rs:61-64
-            const float4 m = S.motion[prim];
-            const float f = (S.flags & kSceneUniformTimes) ? (time - S.u_time0) / S.u_dt : (time - m.w) / S.motion_dt[prim];
-            c = add(c, scale(f, mk(m.x, m.y, m.z)));
+        if (MOVING) {
+            if (S.sph_info[prim] & kInfoMovingBit) {  // sphere.rs:61-64
+                const float4 m = S.motion[prim];
+                const float f = (S.flags & kSceneUniformTimes) ? (time - S.u_time0) / S.u_dt : (time - m.w) / S.motion_dt[prim];
+                c = add(c, scale(f, mk(m.x, m.y, m.z)));
+            }
         }
         // Hit record (sphere.rs:86-100)
         const V3 p = add(o, scale(t, d));
@@ -551,26 +575,23 @@ DEV void shade_slot(const SceneDev &S, const PathState &P, const BatchDev &Bt, u
         const V3 on = mk(pc.x / sp.w, pc.y / sp.w, pc.z / sp.w);
         const bool front = dot3(d, on) < 0.0f;
         const V3 n = front ? on : neg(on);
-        const uint32_t kind = (info >> kInfoKindShift) & 3u;
-        Rng g;
-        g.s0 = in.rng.x; g.s1 = in.rng.y; g.s2 = in.rng.z; g.s3 = in.rng.w;
+        V3 smp = mk(0.0f, 0.0f, 0.0f);
+        if (cls != CL_DIEL) { smp.x = sample_pm1(g); smp.y = sample_pm1(g); smp.z = sample_pm1(g); }  // the draw step 2 accepted
         V3 dir;
         bool scattered = true;
-        if (kind == RRT_MAT_LAMBERTIAN) {  // materials.rs:19-35
-            if (COUNT) ev = ST_HL;
-            const V3 unit = normalized(in_unit_sphere(g));
+        if (cls == CL_LAMB) {  // materials.rs:19-35
+            const V3 unit = normalized(smp);
             dir = add(n, unit);
             if (fabsf(dir.x) < 1e-8f && fabsf(dir.y) < 1e-8f && fabsf(dir.z) < 1e-8f) dir = n;
-        } else if (kind == RRT_MAT_METAL) {  // materials.rs:44-61
-            if (COUNT) ev = ST_HM;
-            const V3 refl = reflected(normalized(d), n);
-            const V3 s = in_unit_sphere(g);
-            dir = add(refl, scale(mt.w, s));
+        } else if (cls == CL_METAL) {  // materials.rs:44-61
+            const float fuzz = S.pmat[prim].w;
+            const V3 refl = reflected(scale_r(d, inv_len), n);
+            dir = add(refl, scale(fuzz, smp));
             scattered = dot3(dir, n) > 0.0f;
         } else {  // materials.rs:75-104
-            if (COUNT) ev = ST_HD;
-            const float ratio = front ? 1.0f / mt.w : mt.w;
-            const V3 ud = normalized(d);
+            const float ref_idx = S.pmat[prim].w;
+            const float ratio = front ? 1.0f / ref_idx : ref_idx;
+            const V3 ud = scale_r(d, inv_len);
             const float cos_theta = fminf(dot3(neg(ud), n), 1.0f);
             const float sin_theta = sqrtf(1.0f - (cos_theta * cos_theta));
             bool reflect = ratio * sin_theta > 1.0f;
@@ -585,12 +606,11 @@ DEV void shade_slot(const SceneDev &S, const PathState &P, const BatchDev &Bt, u
             }
         }
         if (scattered) {
-            P.rayA[slot] = make_float4(p.x, p.y, p.z, time);
-            P.rayB[slot] = make_float4(dir.x, dir.y, dir.z, B.w);
-            P.rayC[slot] = ray_constants(dir);
-            P.rng[slot] = make_uint4(g.s0, g.s1, g.s2, g.s3);
-            const bool on_trail = kind != RRT_MAT_DIELECTRIC;
-            P.depth[slot] = (depth + 1u) | ((trail_len + (on_trail ? 1u : 0u)) << 16);
+            oA = make_float4(p.x, p.y, p.z, time);
+            oB = make_float4(dir.x, dir.y, dir.z, B.w);
+            oC = ray_constants(dir);
+            const bool on_trail = cls != CL_DIEL;
+            o_depth = (depth + 1u) | ((trail_len + (on_trail ? 1u : 0u)) << 16);
             if (on_trail) {
                 // the entry pushed out of the four-deep window goes to the trail planes
                 if (trail_len >= 4u) P.trail[trail_index(P, trail_len - 4u, slot)] = in.recent.w;
@@ -598,90 +618,170 @@ DEV void shade_slot(const SceneDev &S, const PathState &P, const BatchDev &Bt, u
             }
             alive = true;
         } else {  // lib.rs:64
-            if (COUNT) ev = (ev == ST_HM ? ST_HM : ev) | 0x100u;  // absorbed, on top of the material count
-            need = true;
+            absorbed = true;
         }
     }
-    if (need) {
+    if (ended || absorbed) {
         Bt.rad[pid] = rx;
         Bt.rad[(size_t)Bt.rad_plane + pid] = ry;
         Bt.rad[2 * (size_t)Bt.rad_plane + pid] = rz;
     }
+    if (ended) {
+        const uint64_t p64 = path_of_claim(Bt, shard, next_n);
+        if (p64 < (uint64_t)Bt.n_paths) {
+            generate_path(Bt, C, (uint32_t)p64, oA, oB, oC, g);
+            o_depth = 0u;
+            alive = true;
+            started = true;
+        }
+    }
+    if (alive) {
+        P.rayA[slot] = oA;
+        P.rayB[slot] = oB;
+        P.rayC[slot] = oC;
+        P.rng[slot] = make_uint4(g.s0, g.s1, g.s2, g.s3);
+        P.depth[slot] = o_depth;
+    }
 }
 
-// One wave shades its (up to) four tiles.  The live-slot list is read up front, the next tile's state is in flight
-// while the current tile is shaded, all ended paths of the wave claim their replacements with one cursor update, and
-// the live-slot list is rewritten compacted (ballot + prefix popcount) at the end.
 template <bool MOVING, bool COUNT>
 __global__ __launch_bounds__(kBlockThreads) void k_shade(SceneDev S, PathState P, BatchDev Bt, CameraDev C, uint64_t *wave_stats) {
+    __shared__ uint4 lds4[kShadeWavesPerBlock * kShadeLdsWords / 4u];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = P.wave_begin + ((blockIdx.x * kBlockThreads + threadIdx.x) >> 6);
     const uint32_t base = wave * kWaveSlots;
     if (wave >= P.wave_end) return;
     const uint32_t count = rfl(P.qcount[wave]);
     if (count == 0) return;
+    // one 16-byte entry per list position: the slot's generator state; after step 3 the same memory holds step 4's
+    // list of slots to refill
+    uint4 *l_ent = lds4 + (threadIdx.x >> 6) * (kShadeLdsWords / 4u);
+    uint32_t *l_slot = reinterpret_cast<uint32_t *>(l_ent);
     const uint32_t shard = wave % Bt.n_shards;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     static_assert(kWaveSlots == 256, "four list entries per lane");
-    uint32_t q[4];
-    for (uint32_t t = 0; t < 4u; t++) q[t] = lane + 64u * t < count ? P.queue[base + lane + 64u * t] : 0u;
-    const uint32_t n_tiles = (count + 63u) >> 6;
-    uint32_t need_bits = 0, alive_bits = 0;
-    uint32_t c_ev[6] = {0, 0, 0, 0, 0, 0};  // HL, HM, HD, SKY, DEPTHCUT, ABSORBED
 
+    // ---- 1. classify ----
+    uint32_t sq[4];        // the slots at list positions lane + 64 t
+    uint32_t classes = 0;  // class of each of them, 4 bits apiece
+    uint32_t end_rank[4];  // position of a slot among the wave's ending paths (sky, depth limit)
+    uint32_t n_ending = 0;
+    uint32_t c_ev[6] = {0, 0, 0, 0, 0, 0};  // HL, HM, HD, SKY, DEPTHCUT, ABSORBED
+    {
+        uint2 h[4];
+        uint32_t dep[4];
+        uint4 rg[4];
+#pragma unroll
+        for (uint32_t t = 0; t < 4u; t++) sq[t] = lane + 64u * t < count ? P.queue[base + lane + 64u * t] : 0u;
+#pragma unroll
+        for (uint32_t t = 0; t < 4u; t++) {
+            h[t] = make_uint2(0u, 0u); dep[t] = 0u; rg[t] = make_uint4(0u, 0u, 0u, 0u);
+            if (lane + 64u * t < count) { h[t] = P.hit[sq[t]]; dep[t] = P.depth[sq[t]]; rg[t] = P.rng[sq[t]]; }
+        }
+#pragma unroll
+        for (uint32_t t = 0; t < 4u; t++) {
+            uint32_t c;
+            if (!(lane + 64u * t < count)) c = CL_NONE;
+            else if (h[t].y == kPrimNone) c = CL_SKY;
+            else if ((dep[t] & 0xFFFFu) >= Bt.max_depth) c = CL_CUT;
+            else c = h[t].y >> kLeafKindShift;
+            classes |= c << (4u * t);
+            if (c <= CL_DIEL) l_ent[lane + 64u * t] = rg[t];
+            const uint64_t em = __ballot(c == CL_SKY || c == CL_CUT);
+            end_rank[t] = n_ending + (uint32_t)__popcll(em & lt_mask);
+            n_ending += (uint32_t)__popcll(em);
+            if (COUNT) {
+#pragma unroll
+                for (uint32_t k = 0; k < 5u; k++) c_ev[k] += (uint32_t)__popcll(__ballot(c == k));
+            }
+        }
+    }
+    const uint32_t n_tiles = (count + 63u) >> 6;
+    const uint32_t claim0 = claim_paths(Bt, lane, shard, n_ending);
+
+    // the first tile's state travels while the samples are drawn
     SlotIn cur, nxt;
-    load_slot(P, lane < count, q[0], cur);
+    load_slot(P, lane < count, sq[0], cur);
+
+    // ---- 2. in-unit-sphere rejection ----
+    {
+        // bit t set: the slot in column t wants a sample
+        uint32_t todo = 0;
+#pragma unroll
+        for (uint32_t t = 0; t < 4u; t++) todo |= ((classes >> (4u * t)) & 15u) <= CL_METAL ? (1u << t) : 0u;
+        uint32_t idx = 0;
+        Rng g = {0u, 0u, 0u, 0u};
+        if (todo) { idx = lane + 64u * (uint32_t)(__ffs((int)todo) - 1); const uint4 w = l_ent[idx]; g.s0 = w.x; g.s1 = w.y; g.s2 = w.z; g.s3 = w.w; }
+        while (__ballot(todo != 0u) != 0ull) {
+            if (todo) {
+                const Rng before = g;
+                const float x = sample_pm1(g), y = sample_pm1(g), z = sample_pm1(g);
+                if (dot3(mk(x, y, z), mk(x, y, z)) < 1.0f) {
+                    l_ent[idx] = make_uint4(before.s0, before.s1, before.s2, before.s3);
+                    todo &= todo - 1u;
+                    if (todo) { idx = lane + 64u * (uint32_t)(__ffs((int)todo) - 1); const uint4 w = l_ent[idx]; g.s0 = w.x; g.s1 = w.y; g.s2 = w.z; g.s3 = w.w; }
+                }
+            }
+        }
+    }
+
+    // ---- 3. tiles ----
+    uint32_t absorbed_bits = 0, alive_bits = 0;
+    uint32_t n_started = 0;
 #pragma unroll
     for (uint32_t t = 0; t < 4u; t++) {
         if (t < n_tiles) {
-            if (t + 1u < 4u) load_slot(P, lane + 64u * (t + 1u) < count, q[(t + 1u) & 3u], nxt);
-            bool alive = false, need = false;
-            uint32_t ev = 0xFFu;
-            if (lane + 64u * t < count) shade_slot<MOVING, COUNT>(S, P, Bt, q[t], cur, alive, need, ev);
-            need_bits |= need ? (1u << t) : 0u;
+            if (t + 1u < 4u) load_slot(P, lane + 64u * (t + 1u) < count, sq[(t + 1u) & 3u], nxt);
+            const uint32_t pos = lane + 64u * t;
+            const uint32_t cls = (classes >> (4u * t)) & 15u;
+            bool alive = false, absorbed = false, started = false;
+            if (pos < count) shade_slot<MOVING>(S, P, Bt, C, cls, sq[t], cur, l_ent[pos], shard, claim0 + end_rank[t], alive, absorbed, started);
+            absorbed_bits |= absorbed ? (1u << t) : 0u;
             alive_bits |= alive ? (1u << t) : 0u;
-            if (COUNT) {
-                const uint32_t e = ev & 0xFFu;
-                c_ev[0] += (uint32_t)__popcll(__ballot(e == ST_HL)); c_ev[1] += (uint32_t)__popcll(__ballot(e == ST_HM));
-                c_ev[2] += (uint32_t)__popcll(__ballot(e == ST_HD)); c_ev[3] += (uint32_t)__popcll(__ballot(e == ST_SKY));
-                c_ev[4] += (uint32_t)__popcll(__ballot(e == ST_DEPTHCUT)); c_ev[5] += (uint32_t)__popcll(__ballot((ev & 0x100u) != 0u));
-            }
+            n_started += (uint32_t)__popcll(__ballot(started));
             cur = nxt;
         }
     }
-    // ended paths: their slots take the next paths of the batch, if any are left
+
+    // ---- 4. slots whose path was absorbed take the next paths of the batch, if any are left ----
     uint32_t n_need = 0;
-    for (uint32_t t = 0; t < 4u; t++) n_need += (uint32_t)__popcll(__ballot((need_bits >> t) & 1u));
-    uint32_t n_started = 0;
+    uint32_t rank[4];  // position of an absorbed slot in the wave's refill list
+#pragma unroll
+    for (uint32_t t = 0; t < 4u; t++) {
+        const bool need = (absorbed_bits >> t) & 1u;
+        const uint64_t nm = __ballot(need);
+        rank[t] = n_need + (uint32_t)__popcll(nm & lt_mask);
+        if (need) l_slot[rank[t]] = sq[t];
+        n_need += (uint32_t)__popcll(nm);
+    }
+    uint32_t n_refilled = 0;
     if (n_need) {
-        uint32_t n = claim_paths(Bt, lane, shard, n_need);
-        for (uint32_t t = 0; t < 4u; t++) {
-            const bool need = (need_bits >> t) & 1u;
-            const uint64_t nm = __ballot(need);
-            if (nm == 0ull) continue;
+        const uint32_t n = claim_paths(Bt, lane, shard, n_need);
+        for (uint32_t i0 = 0; i0 < n_need; i0 += 64u) {
+            const uint32_t i = i0 + lane;
             bool started = false;
-            if (need) started = start_path(P, Bt, C, shard, n + (uint32_t)__popcll(nm & lt_mask), q[t]);
-            alive_bits |= started ? (1u << t) : 0u;
-            n_started += (uint32_t)__popcll(__ballot(started));
-            n += (uint32_t)__popcll(nm);
+            if (i < n_need) started = start_path(P, Bt, C, shard, n + i, l_slot[i]);
+            n_refilled += (uint32_t)__popcll(__ballot(started));  // path ids grow with i: the paths that still exist are a prefix of the list
         }
     }
-    // compaction of the wave's live-slot list
+
+    // ---- 5. the live-slot list, still in slot order (ballot + prefix popcount) ----
     uint32_t out_count = 0;
+#pragma unroll
     for (uint32_t t = 0; t < 4u; t++) {
-        const bool alive = (alive_bits >> t) & 1u;
+        const bool alive = ((alive_bits >> t) & 1u) || (((absorbed_bits >> t) & 1u) && rank[t] < n_refilled);
         const uint64_t am = __ballot(alive);
-        if (alive) P.queue[base + out_count + (uint32_t)__popcll(am & lt_mask)] = q[t];
+        if (alive) P.queue[base + out_count + (uint32_t)__popcll(am & lt_mask)] = sq[t];
         out_count += (uint32_t)__popcll(am);
     }
     if (lane == 0) {
         P.qcount[wave] = out_count;
         if (out_count && Bt.alive_flag) Bt.alive_flag[(wave & 31u) * 32u] = 1u;  // 32 lines share the traffic
         uint64_t *st = wave_stats + (size_t)wave * kWaveStatWords;
-        st[ST_PATHS] += n_started;
+        st[ST_PATHS] += n_started + n_refilled;
         if (COUNT) {
             st[ST_HL] += c_ev[0]; st[ST_HM] += c_ev[1]; st[ST_HD] += c_ev[2]; st[ST_SKY] += c_ev[3];
-            st[ST_DEPTHCUT] += c_ev[4]; st[ST_ABSORBED] += c_ev[5];
+            st[ST_DEPTHCUT] += c_ev[4]; st[ST_ABSORBED] += (uint32_t)n_need;
         }
     }
 }
@@ -739,7 +839,7 @@ __global__ void k_intersect(SceneDev S, uint32_t n, const float *org, const floa
         if (cur != HbmStore<MOVING>::kEnd) cur = visit_leaf(st, cur, r);
     }
     out_t[i] = r.tmax;
-    out_obj[i] = r.best;
+    out_obj[i] = r.best == kPrimNone ? kPrimNone : (r.best & kLeafPrimMask);
 }
 
 __global__ void k_reduce_stats(const uint64_t *wave_stats, uint32_t n_waves, uint64_t *out16) {

@@ -108,7 +108,7 @@ int build_scene_layout(const rrt_sphere_soa *sp, const rrt_material_soa *mt, con
             const float r = out.sph[p].w;
             w[0] = f2u(out.sph[p].x); w[1] = f2u(out.sph[p].y); w[2] = f2u(out.sph[p].z);
             w[3] = f2u(r * r);  // self.radius * self.radius (sphere.rs:73)
-            w[4] = p;
+            w[4] = p | (((out.sph_info[p] >> kInfoKindShift) & 3u) << kLeafKindShift);  // the hit record carries the material kind along
             w[5] = (out.sph_info[p] & kInfoMovingBit) ? 1u : 0u;
         } else {
             for (int k = 0; k < 3; k++) { w[2 * k] = f2u(n.min[k]); w[2 * k + 1] = f2u(n.max[k]); }
@@ -160,7 +160,7 @@ int build_scene_layout(const rrt_sphere_soa *sp, const rrt_material_soa *mt, con
                 s[6] = ref16(w[7]) | (ref16(w[6] & (kRefLeafBit | kRefIndexMask)) << 16);
                 s[7] = ((w[6] >> RRT_NODE_AXIS_SHIFT) & 3u) * 8u;  // bit offset of the axis' field in the ray's sign word
             } else if (moving && (w[5] & 1u)) {
-                const Float4 &m = out.motion[w[4]];
+                const Float4 &m = out.motion[w[4] & kLeafPrimMask];
                 s[12] = f2u(m.x); s[13] = f2u(m.y); s[14] = f2u(m.z);
             }
             for (int o = 0; o < 8; o += 2) s[8 + o / 2] = ref16(w[8 + o]) | (ref16(w[8 + o + 1]) << 16);

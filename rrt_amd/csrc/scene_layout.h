@@ -19,6 +19,8 @@ constexpr uint32_t kRefLeafBit = 0x80000000u;   // a node reference that points 
 constexpr uint32_t kRefEnd = 0x7FFFFFFFu;       // "nothing left to visit"
 constexpr uint32_t kRefIndexMask = 0x1FFFFFFFu; // node index inside a reference
 constexpr uint32_t kNodeWords = 16;             // 64 bytes
+constexpr uint32_t kLeafPrimMask = 0x3FFFFFFFu; // leaf word 4: sphere index | material kind << 30
+constexpr uint32_t kLeafKindShift = 30;
 
 // Compact layout for scenes small enough to live in a workgroup's LDS.  A 16-bit reference is the node's offset in
 // 16-byte units (at most 4095 inside the 64 KB budget) with bit 15 set for a leaf.
@@ -41,7 +43,7 @@ struct Float4 { float x, y, z, w; };
 
 struct SceneLayout {
     // Node words.  Inner: [0..5] box as (min, max) per axis: x, y, z, [6] right ref | axis << 29, [7] left ref,
-    // [8..15] exit link per octant.  Leaf: [0..2] centre at time0, [3] radius^2, [4] sphere index,
+    // [8..15] exit link per octant.  Leaf: [0..2] centre at time0, [3] radius^2, [4] sphere index | material kind << 30,
     // [5] bit 0 = moving, [8..15] exit link per octant.
     std::vector<uint32_t> nodes;
     uint32_t n_nodes = 0;
