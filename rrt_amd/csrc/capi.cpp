@@ -264,7 +264,7 @@ int render_impl(rrt_ctx *c, const rrt_render_params *pp, void *d_rgb8, void *d_a
     const bool time_kernels = count || P.reserved[0] != 0;
     if (npix > 0 && ns_local > 0) {
         // ---- batch and slot sizing ----
-        uint32_t batch = P.batch_samples ? P.batch_samples : (uint32_t)std::max<size_t>(1, kRadBudgetBytes / ((size_t)npix * 12));
+        uint32_t batch = P.batch_samples ? P.batch_samples : (uint32_t)std::max<size_t>(1, kRadBudgetBytes / ((size_t)npix * 16));
         batch = std::min(batch, ns_local);
         batch = std::min<uint32_t>(batch, std::max<uint32_t>(1, kMaxBatchPaths / npix));
         const uint32_t rad_plane = batch * npix;
@@ -281,7 +281,7 @@ int render_impl(rrt_ctx *c, const rrt_render_params *pp, void *d_rgb8, void *d_a
         HIP_TRY(c->wave_stats.ensure((size_t)n_waves * kWaveStatWords * 8));
         HIP_TRY(c->cursors.ensure((size_t)kCursorShards * kCursorStride * 4));
         HIP_TRY(c->flags.ensure(kFlagWords * 4)); HIP_TRY(c->stats_out.ensure(kWaveStatWords * 8));
-        HIP_TRY(c->accum.ensure((size_t)npix * 12)); HIP_TRY(c->rad.ensure((size_t)rad_plane * 12));
+        HIP_TRY(c->accum.ensure((size_t)npix * 12)); HIP_TRY(c->rad.ensure((size_t)rad_plane * 16));
 
         PathState ps{};
         ps.rayA = c->rayA.as<float4>(); ps.rayB = c->rayB.as<float4>(); ps.rayC = c->rayC.as<float4>(); ps.recent = c->recent.as<uint4>(); ps.rng = c->rng.as<uint4>();
@@ -309,7 +309,7 @@ int render_impl(rrt_ctx *c, const rrt_render_params *pp, void *d_rgb8, void *d_a
             bd.n_paths = nb * npix;
             bd.k_first = k_first + s0 * k_step; bd.k_step = k_step;
             bd.seed = P.seed;
-            bd.rad = c->rad.as<float>(); bd.rad_plane = rad_plane;
+            bd.rad = c->rad.as<float4>();
             bd.max_depth = P.max_depth;
             bd.cursors = c->cursors.as<uint32_t>();
             bd.n_shards = std::min(kCursorShards, n_waves);
@@ -344,7 +344,7 @@ int render_impl(rrt_ctx *c, const rrt_render_params *pp, void *d_rgb8, void *d_a
                 for (uint32_t k = 0; k < kFlagWords; k += 32) any |= c->h_flags[k];
                 if (!any) break;
             }
-            launch_accumulate(s, c->accum.as<float>(), npix, c->rad.as<float>(), rad_plane, nb, s0 == 0);
+            launch_accumulate(s, c->accum.as<float>(), npix, c->rad.as<float4>(), nb, s0 == 0);
         }
         launch_finalize(s, c->accum.as<float>(), npix, d_map, P.ns, static_cast<uint8_t *>(d_rgb8), static_cast<float *>(d_accum));
         launch_reduce_stats(s, wstats, n_waves, c->stats_out.as<uint64_t>());

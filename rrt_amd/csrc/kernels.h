@@ -65,8 +65,7 @@ struct BatchDev {
     uint32_t n_paths;          // npix * samples in this batch
     uint32_t k_first, k_step;  // sample index of local sample j is k_first + j * k_step
     uint64_t seed;
-    float *rad;                // 3 planes of rad_plane floats: radiance of each path of the batch
-    uint32_t rad_plane;
+    float4 *rad;               // radiance (r, g, b, unused) of each path of the batch, by path id
     uint32_t max_depth;
     uint32_t *cursors;         // n_shards counters, kCursorStride words apart
     uint32_t n_shards;         // min(kCursorShards, waves): every shard must be served by at least one wave
@@ -78,8 +77,8 @@ void launch_extend(hipStream_t s, const SceneDev &S, const PathState &P, bool mo
                    uint32_t leaf_min, uint64_t *wave_stats);
 void launch_shade(hipStream_t s, const SceneDev &S, const PathState &P, const BatchDev &B, const CameraDev &C, bool moving,
                   bool count, uint64_t *wave_stats);
-// accum[3][npix] += rad planes, sample by sample in order (lib.rs:96-103)
-void launch_accumulate(hipStream_t s, float *accum, uint32_t npix, const float *rad, uint32_t rad_plane, uint32_t n_samples,
+// accum[3][npix] += radiance of the batch's paths, sample by sample in order (lib.rs:96-103)
+void launch_accumulate(hipStream_t s, float *accum, uint32_t npix, const float4 *rad, uint32_t n_samples,
                        bool first_batch);
 // lib.rs:105-108 for local pixel planes -> interleaved RGB8 / float sums at image positions
 void launch_finalize(hipStream_t s, const float *accum, uint32_t npix, const uint32_t *pixel_map, uint32_t ns, uint8_t *rgb8,

@@ -511,6 +511,7 @@ DEV void shade_slot(const SceneDev &S, const PathState &P, const BatchDev &Bt, c
     Rng g;
     g.s0 = gw.x; g.s1 = gw.y; g.s2 = gw.z; g.s3 = gw.w;
     uint32_t o_depth = 0u;
+    uint4 o_recent = in.recent;
     bool ended = false;
     // 1 / |d|, shared by everything that needs the unit direction: the sky (lib.rs:67), metal (materials.rs:47) and glass (materials.rs:83)
     float inv_len = 0.0f;
@@ -614,7 +615,7 @@ DEV void shade_slot(const SceneDev &S, const PathState &P, const BatchDev &Bt, c
             if (on_trail) {
                 // the entry pushed out of the four-deep window goes to the trail planes
                 if (trail_len >= 4u) P.trail[trail_index(P, trail_len - 4u, slot)] = in.recent.w;
-                P.recent[slot] = make_uint4(prim, in.recent.x, in.recent.y, in.recent.z);
+                o_recent = make_uint4(prim, in.recent.x, in.recent.y, in.recent.z);
             }
             alive = true;
         } else {  // lib.rs:64
@@ -622,9 +623,7 @@ DEV void shade_slot(const SceneDev &S, const PathState &P, const BatchDev &Bt, c
         }
     }
     if (ended || absorbed) {
-        Bt.rad[pid] = rx;
-        Bt.rad[(size_t)Bt.rad_plane + pid] = ry;
-        Bt.rad[2 * (size_t)Bt.rad_plane + pid] = rz;
+        Bt.rad[pid] = make_float4(rx, ry, rz, 0.0f);  // one 16-byte store per finished path
     }
     if (ended) {
         const uint64_t p64 = path_of_claim(Bt, shard, next_n);
@@ -641,6 +640,7 @@ DEV void shade_slot(const SceneDev &S, const PathState &P, const BatchDev &Bt, c
         P.rayC[slot] = oC;
         P.rng[slot] = make_uint4(g.s0, g.s1, g.s2, g.s3);
         P.depth[slot] = o_depth;
+        P.recent[slot] = o_recent;  // also where nothing changed: a store that covers whole lines costs the memory system less than a sparse one
     }
 }
 
@@ -661,6 +661,9 @@ __global__ __launch_bounds__(kBlockThreads) void k_shade(SceneDev S, PathState P
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     static_assert(kWaveSlots == 256, "four list entries per lane");
 
+#ifdef RRT_SHADE_TIMING
+    const uint64_t tk0 = __builtin_readcyclecounter();
+#endif
     // ---- 1. classify ----
     uint32_t sq[4];        // the slots at list positions lane + 64 t
     uint32_t classes = 0;  // class of each of them, 4 bits apiece
@@ -703,6 +706,9 @@ __global__ __launch_bounds__(kBlockThreads) void k_shade(SceneDev S, PathState P
     SlotIn cur, nxt;
     load_slot(P, lane < count, sq[0], cur);
 
+#ifdef RRT_SHADE_TIMING
+    const uint64_t tk1 = __builtin_readcyclecounter();
+#endif
     // ---- 2. in-unit-sphere rejection ----
     {
         // bit t set: the slot in column t wants a sample
@@ -725,6 +731,9 @@ __global__ __launch_bounds__(kBlockThreads) void k_shade(SceneDev S, PathState P
         }
     }
 
+#ifdef RRT_SHADE_TIMING
+    const uint64_t tk2 = __builtin_readcyclecounter();
+#endif
     // ---- 3. tiles ----
     uint32_t absorbed_bits = 0, alive_bits = 0;
     uint32_t n_started = 0;
@@ -743,6 +752,9 @@ __global__ __launch_bounds__(kBlockThreads) void k_shade(SceneDev S, PathState P
         }
     }
 
+#ifdef RRT_SHADE_TIMING
+    const uint64_t tk3 = __builtin_readcyclecounter();
+#endif
     // ---- 4. slots whose path was absorbed take the next paths of the batch, if any are left ----
     uint32_t n_need = 0;
     uint32_t rank[4];  // position of an absorbed slot in the wave's refill list
@@ -765,6 +777,9 @@ __global__ __launch_bounds__(kBlockThreads) void k_shade(SceneDev S, PathState P
         }
     }
 
+#ifdef RRT_SHADE_TIMING
+    const uint64_t tk4 = __builtin_readcyclecounter();
+#endif
     // ---- 5. the live-slot list, still in slot order (ballot + prefix popcount) ----
     uint32_t out_count = 0;
 #pragma unroll
@@ -779,6 +794,9 @@ __global__ __launch_bounds__(kBlockThreads) void k_shade(SceneDev S, PathState P
         if (out_count && Bt.alive_flag) Bt.alive_flag[(wave & 31u) * 32u] = 1u;  // 32 lines share the traffic
         uint64_t *st = wave_stats + (size_t)wave * kWaveStatWords;
         st[ST_PATHS] += n_started + n_refilled;
+#ifdef RRT_SHADE_TIMING
+        { const uint64_t tk5 = __builtin_readcyclecounter(); st[10] += tk1 - tk0; st[11] += tk2 - tk1; st[12] += tk3 - tk2; st[13] += tk4 - tk3; st[14] += tk5 - tk4; st[15] += 1; }
+#endif
         if (COUNT) {
             st[ST_HL] += c_ev[0]; st[ST_HM] += c_ev[1]; st[ST_HD] += c_ev[2]; st[ST_SKY] += c_ev[3];
             st[ST_DEPTHCUT] += c_ev[4]; st[ST_ABSORBED] += (uint32_t)n_need;
@@ -786,15 +804,16 @@ __global__ __launch_bounds__(kBlockThreads) void k_shade(SceneDev S, PathState P
     }
 }
 
-__global__ void k_accumulate(float *accum, uint32_t npix, const float *rad, uint32_t rad_plane, uint32_t n_samples, int first) {
+__global__ void k_accumulate(float *accum, uint32_t npix, const float4 *rad, uint32_t n_samples, int first) {
     const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= npix) return;
-    for (uint32_t c = 0; c < 3u; c++) {
-        float acc = first ? 0.0f : accum[(size_t)c * npix + l];
-        const float *r = rad + (size_t)c * rad_plane + l;
-        for (uint32_t s = 0; s < n_samples; s++) acc += r[(size_t)s * npix];  // c += trace(..) (lib.rs:102)
-        accum[(size_t)c * npix + l] = acc;
+    float ax = first ? 0.0f : accum[l], ay = first ? 0.0f : accum[(size_t)npix + l], az = first ? 0.0f : accum[2 * (size_t)npix + l];
+    const float4 *r = rad + l;
+    for (uint32_t s = 0; s < n_samples; s++) {  // c += trace(..) (lib.rs:102), sample by sample
+        const float4 v = r[(size_t)s * npix];
+        ax += v.x; ay += v.y; az += v.z;
     }
+    accum[l] = ax; accum[(size_t)npix + l] = ay; accum[2 * (size_t)npix + l] = az;
 }
 
 // Rust `as u8`: saturating, NaN -> 0, truncation toward zero (lib.rs:106-108)
@@ -901,9 +920,9 @@ void launch_shade(hipStream_t s, const SceneDev &S, const PathState &P, const Ba
     }
 }
 
-void launch_accumulate(hipStream_t s, float *accum, uint32_t npix, const float *rad, uint32_t rad_plane, uint32_t n_samples,
+void launch_accumulate(hipStream_t s, float *accum, uint32_t npix, const float4 *rad, uint32_t n_samples,
                        bool first_batch) {
-    hipLaunchKernelGGL(k_accumulate, dim3((npix + 255u) / 256u), dim3(256), 0, s, accum, npix, rad, rad_plane, n_samples,
+    hipLaunchKernelGGL(k_accumulate, dim3((npix + 255u) / 256u), dim3(256), 0, s, accum, npix, rad, n_samples,
                        first_batch ? 1 : 0);
 }
 
