@@ -179,6 +179,7 @@ int rrt_upload_scene(rrt_ctx *c, const rrt_sphere_soa *sp, const rrt_material_so
     c->sd.small_words = L.small_words;
     c->sd.small_root = L.small_root;
     c->sd.n_nodes = L.n_nodes;
+    c->sd.n_spheres = L.n_spheres;
     c->moving = (L.flags & kSceneHasMoving) != 0;
     c->n_spheres = L.n_spheres;
     c->n_nodes = L.n_nodes;

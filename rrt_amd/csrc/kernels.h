@@ -30,7 +30,7 @@ struct SceneDev {
     const uint32_t *sph_info;
     const float4 *mat;        // {albedo, fuzz | ref_idx} per material
     const float4 *pmat;       // the same, per sphere: one gather less in shade
-    const float4 *prim_att;   // attenuation per sphere
+    const float4 *prim_att;   // per sphere: attenuation rgb, fuzz or ref_idx
     uint32_t flags;
     float u_time0, u_dt;
     // compact copy for LDS residency (null when the scene does not qualify; see scene_layout.h)
@@ -38,6 +38,7 @@ struct SceneDev {
     uint32_t small_words;   // 12 or 16 words per node
     uint32_t small_root;    // 16-bit reference of the root
     uint32_t n_nodes;
+    uint32_t n_spheres;
 };
 
 // All per-path state lives in planes indexed by slot.  A wave owns slots [wave*kWaveSlots, +kWaveSlots)

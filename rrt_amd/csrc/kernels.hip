@@ -9,6 +9,8 @@
 //
 // Arithmetic follows the reference operation for operation: compiled with -ffp-contract=off, fused
 // multiply-adds only where ultraviolet's dot/mag use mul_add, IEEE division and square root.
+#include <type_traits>
+
 #include "kernels.h"
 #include "scene_layout.h"
 
@@ -481,7 +483,8 @@ static_assert(RRT_MAT_LAMBERTIAN == CL_LAMB && RRT_MAT_METAL == CL_METAL && RRT_
 
 // LDS words per wave: one 16-byte entry per list position
 constexpr uint32_t kShadeLdsWords = kWaveSlots * 4u;
-constexpr uint32_t kShadeWavesPerBlock = kBlockThreads / 64u;
+constexpr uint32_t kShadeTableThreads = 512;   // block size of the variant that keeps the per-sphere tables in LDS
+constexpr uint32_t kShadeTableSpheres = 512;   // and the largest scene it takes: 2 x 16 bytes per sphere
 
 // What step 3 reads of one path slot
 struct SlotIn {
@@ -494,10 +497,23 @@ DEV void load_slot(const PathState &P, bool active, uint32_t slot, SlotIn &in) {
     if (active) { in.A = P.rayA[slot]; in.B = P.rayB[slot]; in.h = P.hit[slot]; in.depth = P.depth[slot]; in.recent = P.recent[slot]; }
 }
 
+// Where shade reads the per-sphere tables from: HBM through the caches, or (small scenes) a copy in the block's LDS.  An
+// LDS read does not queue behind the kernel's outstanding stores the way a global load does.
+struct GlobalTables {
+    const float4 *sph, *att;
+    DEV float4 sphere(uint32_t i) const { return sph[i]; }
+    DEV float4 material(uint32_t i) const { return att[i]; }
+};
+struct LdsTables {
+    const float4 *sph, *att;  // both in LDS
+    DEV float4 sphere(uint32_t i) const { return sph[i]; }
+    DEV float4 material(uint32_t i) const { return att[i]; }
+};
+
 // Step 3 for one lane.  `gw` is the slot's LDS entry: the generator state (before the accepted draw, for Lambertian and
 // metal).  `next_n` is the claim number of the path that takes over the slot if this one ends here.
-template <bool MOVING>
-DEV void shade_slot(const SceneDev &S, const PathState &P, const BatchDev &Bt, const CameraDev &C, uint32_t cls, uint32_t slot,
+template <bool MOVING, class Tables>
+DEV void shade_slot(const SceneDev &S, const Tables &T, const PathState &P, const BatchDev &Bt, const CameraDev &C, uint32_t cls, uint32_t slot,
                     const SlotIn &in, uint4 gw, uint32_t shard, uint32_t next_n, bool &alive, bool &absorbed, bool &started) {
     const float4 A = in.A, B = in.B;
     const uint32_t depth = in.depth & 0xFFFFu;       // scatters so far
@@ -533,7 +549,7 @@ DEV void shade_slot(const SceneDev &S, const PathState &P, const BatchDev &Bt, c
             const uint32_t w4[4] = {in.recent.x, in.recent.y, in.recent.z, in.recent.w};
             float4 at[4];
 #pragma unroll
-            for (uint32_t k = 0; k < 4u; k++) at[k] = S.prim_att[k < trail_len ? w4[k] : 0u];
+            for (uint32_t k = 0; k < 4u; k++) at[k] = T.material(k < trail_len ? w4[k] : 0u);
 #pragma unroll
             for (uint32_t k = 0; k < 4u; k++)
                 if (k < trail_len) { rx = at[k].x * rx; ry = at[k].y * ry; rz = at[k].z * rz; }
@@ -548,7 +564,7 @@ DEV void shade_slot(const SceneDev &S, const PathState &P, const BatchDev &Bt, c
             for (uint32_t half = 0; half < 8u; half += 4u) {
                 float4 at[4];
 #pragma unroll
-                for (uint32_t k = 0; k < 4u; k++) at[k] = S.prim_att[pr[half + k]];
+                for (uint32_t k = 0; k < 4u; k++) at[k] = T.material(pr[half + k]);
 #pragma unroll
                 for (uint32_t k = 0; k < 4u; k++)
                     if (half + k < m) { rx = at[k].x * rx; ry = at[k].y * ry; rz = at[k].z * rz; }
@@ -561,7 +577,8 @@ DEV void shade_slot(const SceneDev &S, const PathState &P, const BatchDev &Bt, c
     } else if (cls != CL_NONE) {
         const uint32_t prim = in.h.y & kLeafPrimMask;
         const float t = u2f(in.h.x);
-        const float4 sp = S.sph[prim];
+        const float4 sp = T.sphere(prim);
+        const float mat_param = T.material(prim).w;  // fuzz or ref_idx
         V3 c = mk(sp.x, sp.y, sp.z);
         if (MOVING) {
             if (S.sph_info[prim] & kInfoMovingBit) {  // sphere.rs:61-64
@@ -585,12 +602,12 @@ DEV void shade_slot(const SceneDev &S, const PathState &P, const BatchDev &Bt, c
             dir = add(n, unit);
             if (fabsf(dir.x) < 1e-8f && fabsf(dir.y) < 1e-8f && fabsf(dir.z) < 1e-8f) dir = n;
         } else if (cls == CL_METAL) {  // materials.rs:44-61
-            const float fuzz = S.pmat[prim].w;
+            const float fuzz = mat_param;
             const V3 refl = reflected(scale_r(d, inv_len), n);
             dir = add(refl, scale(fuzz, smp));
             scattered = dot3(dir, n) > 0.0f;
         } else {  // materials.rs:75-104
-            const float ref_idx = S.pmat[prim].w;
+            const float ref_idx = mat_param;
             const float ratio = front ? 1.0f / ref_idx : ref_idx;
             const V3 ud = scale_r(d, inv_len);
             const float cos_theta = fminf(dot3(neg(ud), n), 1.0f);
@@ -644,11 +661,26 @@ DEV void shade_slot(const SceneDev &S, const PathState &P, const BatchDev &Bt, c
     }
 }
 
-template <bool MOVING, bool COUNT>
-__global__ __launch_bounds__(kBlockThreads) void k_shade(SceneDev S, PathState P, BatchDev Bt, CameraDev C, uint64_t *wave_stats) {
-    __shared__ uint4 lds4[kShadeWavesPerBlock * kShadeLdsWords / 4u];
+template <bool MOVING, bool COUNT, bool TABLES>
+__global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads) void k_shade(SceneDev S, PathState P, BatchDev Bt, CameraDev C,
+                                                                                      uint64_t *wave_stats) {
+    constexpr uint32_t kThreads = TABLES ? kShadeTableThreads : kBlockThreads;
+    extern __shared__ uint4 lds4[];  // per wave kShadeLdsWords words, then (TABLES) the sphere and material tables
+    using Tables = typename std::conditional<TABLES, LdsTables, GlobalTables>::type;
+    Tables T;
+    if (TABLES) {
+        uint4 *tab = lds4 + (kThreads / 64u) * (kShadeLdsWords / 4u);
+        const uint4 *src_s = reinterpret_cast<const uint4 *>(S.sph), *src_a = reinterpret_cast<const uint4 *>(S.prim_att);
+        for (uint32_t i = threadIdx.x; i < S.n_spheres; i += kThreads) { tab[i] = src_s[i]; tab[S.n_spheres + i] = src_a[i]; }
+        __syncthreads();
+        T.sph = reinterpret_cast<const float4 *>(tab);
+        T.att = reinterpret_cast<const float4 *>(tab + S.n_spheres);
+    } else {
+        T.sph = S.sph;
+        T.att = S.prim_att;
+    }
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = P.wave_begin + ((blockIdx.x * kBlockThreads + threadIdx.x) >> 6);
+    const uint32_t wave = P.wave_begin + ((blockIdx.x * kThreads + threadIdx.x) >> 6);
     const uint32_t base = wave * kWaveSlots;
     if (wave >= P.wave_end) return;
     const uint32_t count = rfl(P.qcount[wave]);
@@ -744,7 +776,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_shade(SceneDev S, PathState P
             const uint32_t pos = lane + 64u * t;
             const uint32_t cls = (classes >> (4u * t)) & 15u;
             bool alive = false, absorbed = false, started = false;
-            if (pos < count) shade_slot<MOVING>(S, P, Bt, C, cls, sq[t], cur, l_ent[pos], shard, claim0 + end_rank[t], alive, absorbed, started);
+            if (pos < count) shade_slot<MOVING, Tables>(S, T, P, Bt, C, cls, sq[t], cur, l_ent[pos], shard, claim0 + end_rank[t], alive, absorbed, started);
             absorbed_bits |= absorbed ? (1u << t) : 0u;
             alive_bits |= alive ? (1u << t) : 0u;
             n_started += (uint32_t)__popcll(__ballot(started));
@@ -910,13 +942,28 @@ void launch_extend(hipStream_t s, const SceneDev &S, const PathState &P, bool mo
 
 void launch_shade(hipStream_t s, const SceneDev &S, const PathState &P, const BatchDev &B, const CameraDev &C, bool moving,
                   bool count, uint64_t *wave_stats) {
+    const uint32_t n_waves = P.wave_end - P.wave_begin;
+    if (S.n_spheres <= kShadeTableSpheres) {
+        const uint32_t wpb = kShadeTableThreads / 64u;
+        const dim3 g((n_waves + wpb - 1u) / wpb), b(kShadeTableThreads);
+        const size_t lds = (size_t)wpb * kShadeLdsWords * 4u + (size_t)S.n_spheres * 32u;
+        if (moving) {
+            if (count) hipLaunchKernelGGL((k_shade<true, true, true>), g, b, lds, s, S, P, B, C, wave_stats);
+            else hipLaunchKernelGGL((k_shade<true, false, true>), g, b, lds, s, S, P, B, C, wave_stats);
+        } else {
+            if (count) hipLaunchKernelGGL((k_shade<false, true, true>), g, b, lds, s, S, P, B, C, wave_stats);
+            else hipLaunchKernelGGL((k_shade<false, false, true>), g, b, lds, s, S, P, B, C, wave_stats);
+        }
+        return;
+    }
     const dim3 g(wave_grid(P)), b(kBlockThreads);
+    const size_t lds = (size_t)(kBlockThreads / 64u) * kShadeLdsWords * 4u;
     if (moving) {
-        if (count) hipLaunchKernelGGL((k_shade<true, true>), g, b, 0, s, S, P, B, C, wave_stats);
-        else hipLaunchKernelGGL((k_shade<true, false>), g, b, 0, s, S, P, B, C, wave_stats);
+        if (count) hipLaunchKernelGGL((k_shade<true, true, false>), g, b, lds, s, S, P, B, C, wave_stats);
+        else hipLaunchKernelGGL((k_shade<true, false, false>), g, b, lds, s, S, P, B, C, wave_stats);
     } else {
-        if (count) hipLaunchKernelGGL((k_shade<false, true>), g, b, 0, s, S, P, B, C, wave_stats);
-        else hipLaunchKernelGGL((k_shade<false, false>), g, b, 0, s, S, P, B, C, wave_stats);
+        if (count) hipLaunchKernelGGL((k_shade<false, true, false>), g, b, lds, s, S, P, B, C, wave_stats);
+        else hipLaunchKernelGGL((k_shade<false, false, false>), g, b, lds, s, S, P, B, C, wave_stats);
     }
 }
 

@@ -60,8 +60,8 @@ int build_scene_layout(const rrt_sphere_soa *sp, const rrt_material_soa *mt, con
         out.motion_dt[i] = sp->time1[i] - sp->time0[i];
         out.sph_info[i] = m | (mt->kind[m] << kInfoKindShift) | (still ? 0u : kInfoMovingBit);
         out.pmat[i] = out.mat[m];
-        if (mt->kind[m] == RRT_MAT_DIELECTRIC) out.prim_att[i] = Float4{1.f, 1.f, 1.f, 0.f};
-        else out.prim_att[i] = Float4{mt->albedo_r[m], mt->albedo_g[m], mt->albedo_b[m], 1.f};
+        if (mt->kind[m] == RRT_MAT_DIELECTRIC) out.prim_att[i] = Float4{1.f, 1.f, 1.f, out.mat[m].w};
+        else out.prim_att[i] = Float4{mt->albedo_r[m], mt->albedo_g[m], mt->albedo_b[m], out.mat[m].w};
         if (!still) {
             if (!any_moving) { ut0 = f2u(sp->time0[i]); ut1 = f2u(sp->time1[i]); out.u_time0 = sp->time0[i]; out.u_dt = out.motion_dt[i]; }
             else if (ut0 != f2u(sp->time0[i]) || ut1 != f2u(sp->time1[i])) uniform = false;
