@@ -47,7 +47,9 @@ struct DevBuf {
 constexpr uint32_t kDefaultSlots = 1u << 22;
 constexpr size_t kRadBudgetBytes = size_t(16) << 30;  // per-batch radiance planes; HBM is 288 GB
 constexpr uint32_t kMaxBatchPaths = 1u << 30;
-constexpr uint32_t kFlagWords = 2 * 32 * 32;  // per half: 32 flag words, one per 128-byte line
+constexpr uint32_t kMaxParts = 4;       // parts of the path pool that run on streams of their own
+constexpr uint32_t kDefaultParts = 2;
+constexpr uint32_t kFlagWords = kMaxParts * 32 * 32;  // per part: 32 flag words, one per 128-byte line
 constexpr uint32_t kChunk = 8;  // extend+shade rounds queued between two looks at the alive flag
 constexpr uint32_t kMaxDepthLimit = 4096;  // depth and trail length share one 32-bit word per path
 
@@ -55,8 +57,8 @@ constexpr uint32_t kMaxDepthLimit = 4096;  // depth and trail length share one 3
 
 struct rrt_ctx {
     int device = 0;
-    hipStream_t stream = nullptr, stream2 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_ext[2] = {nullptr, nullptr}, ev_shd[2] = {nullptr, nullptr};
+    hipStream_t stream = nullptr, side_stream[kMaxParts - 1] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[kMaxParts - 1] = {};
     hipDeviceProp_t prop{};
     // scene
     DevBuf nodes, small_nodes, sph, motion, motion_dt, sph_info, mat, pmat, prim_att;
@@ -81,6 +83,15 @@ extern "C" {
 const char *rrt_last_error(void) { return g_err.c_str(); }
 const char *rrt_version(void) { return "rrt_amd 0.1 (gfx950)"; }
 
+namespace {
+bool make_side_streams(rrt_ctx *c) {
+    for (uint32_t i = 0; i + 1 < kMaxParts; i++)
+        if (hipStreamCreateWithFlags(&c->side_stream[i], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) != hipSuccess) return false;
+    return true;
+}
+}  // namespace
+
 int rrt_create(int device, rrt_ctx **out) {
     if (!out) return fail(RRT_ERR_INVALID_ARGUMENT, "rrt_create: out is null");
     *out = nullptr;
@@ -93,13 +104,7 @@ int rrt_create(int device, rrt_ctx **out) {
     rrt_ctx *c = new rrt_ctx();
     c->device = device;
     if (hipGetDeviceProperties(&c->prop, device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_ext[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_ext[1], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_shd[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_shd[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || !make_side_streams(c) ||
         hipHostMalloc(reinterpret_cast<void **>(&c->h_flags), sizeof(uint32_t) * kFlagWords, hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&c->h_stats), sizeof(uint64_t) * kWaveStatWords, hipHostMallocDefault) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
@@ -114,7 +119,7 @@ void rrt_destroy(rrt_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    for (hipStream_t ss : c->side_stream) if (ss) (void)hipStreamSynchronize(ss);
     for (DevBuf *b : {&c->nodes, &c->small_nodes, &c->sph, &c->motion, &c->motion_dt, &c->sph_info, &c->mat, &c->pmat, &c->prim_att, &c->rayA, &c->rayB, &c->rayC, &c->recent, &c->rng,
                       &c->depth, &c->hit, &c->trail, &c->queue, &c->qcount, &c->wave_stats, &c->cursors, &c->flags, &c->stats_out,
                       &c->accum, &c->rad, &c->pixel_map, &c->tmp_rgb, &c->tmp_acc, &c->q_org, &c->q_dir, &c->q_time, &c->q_t, &c->q_obj})
@@ -124,10 +129,9 @@ void rrt_destroy(rrt_ctx *c) {
     if (c->h_stats) (void)hipHostFree(c->h_stats);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
-    for (hipEvent_t ev : {c->ev_ext[0], c->ev_ext[1], c->ev_shd[0], c->ev_shd[1]}) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : c->ev_join) if (ev) (void)hipEventDestroy(ev);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    for (hipStream_t ss : c->side_stream) if (ss) (void)hipStreamDestroy(ss);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -293,15 +297,21 @@ int render_impl(rrt_ctx *c, const rrt_render_params *pp, void *d_rgb8, void *d_a
         HIP_TRY(hipMemsetAsync(wstats, 0, (size_t)n_waves * kWaveStatWords * 8, s));
         uint32_t *flags = c->flags.as<uint32_t>();
 
-        // The path pool is worked on in two halves.  All extend launches go to one stream and all shade launches to a
-        // second one, chained by events (extend(h) -> shade(h) -> next extend(h)), so that the extend kernel of one half
-        // (VALU-bound) always runs beside the shade kernel of the other half (bound by memory latency).
+        // The path pool is worked on in parts, each with its own stream running extend, shade, extend, ... freely, so
+        // that the extend kernel of one part (VALU-bound) runs beside the shade kernel of another (bound by memory
+        // latency).  RRT_STREAMS=1..4 picks the number of parts.
         const char *env_streams = std::getenv("RRT_STREAMS");
-        const uint32_t n_half = (n_waves >= 64 && !(env_streams && env_streams[0] == '1')) ? 2u : 1u;
-        const bool free_run = !(env_streams && env_streams[0] == '2');  // '2': alternate the halves strictly through events (slower)
-        hipStream_t s_ext0 = s, s_shd0 = n_half == 2 ? c->stream2 : s;
-        PathState half[2] = {ps, ps};
-        if (n_half == 2) { half[0].wave_end = n_waves / 2; half[1].wave_begin = n_waves / 2; }
+        uint32_t n_parts = kDefaultParts;
+        if (env_streams && env_streams[0] >= '1' && env_streams[0] <= '0' + (int)kMaxParts) n_parts = (uint32_t)(env_streams[0] - '0');
+        if (n_waves < 32 * n_parts) n_parts = 1;
+        PathState part[kMaxParts];
+        hipStream_t part_stream[kMaxParts];
+        for (uint32_t h = 0; h < n_parts; h++) {
+            part[h] = ps;
+            part[h].wave_begin = (uint32_t)((uint64_t)n_waves * h / n_parts);
+            part[h].wave_end = (uint32_t)((uint64_t)n_waves * (h + 1) / n_parts);
+            part_stream[h] = h == 0 ? s : c->side_stream[h - 1];
+        }
 
         for (uint32_t s0 = 0; s0 < ns_local; s0 += batch) {
             const uint32_t nb = std::min(batch, ns_local - s0);
@@ -319,26 +329,26 @@ int render_impl(rrt_ctx *c, const rrt_render_params *pp, void *d_rgb8, void *d_a
             launch_raygen(s, ps, bd, c->cam, wstats);
             for (;;) {
                 HIP_TRY(hipMemsetAsync(flags, 0, kFlagWords * 4, s));
-                if (n_half == 2) { HIP_TRY(hipEventRecord(c->ev_fork, s)); HIP_TRY(hipStreamWaitEvent(s_shd0, c->ev_fork, 0)); }
+                if (n_parts > 1) {
+                    HIP_TRY(hipEventRecord(c->ev_fork, s));
+                    for (uint32_t h = 1; h < n_parts; h++) HIP_TRY(hipStreamWaitEvent(part_stream[h], c->ev_fork, 0));
+                }
                 for (uint32_t it = 0; it < kChunk; it++) {
-                    for (uint32_t h = 0; h < n_half; h++) {
-                        hipStream_t s_ext = free_run ? (h ? s_shd0 : s_ext0) : s_ext0, s_shd = free_run ? s_ext : s_shd0;
-                        if (n_half == 2 && it > 0 && !free_run) HIP_TRY(hipStreamWaitEvent(s_ext, c->ev_shd[h], 0));  // the half's previous shade
+                    for (uint32_t h = 0; h < n_parts; h++) {
+                        hipStream_t sp = part_stream[h];
                         if (time_kernels) {
                             while (c->kev.size() < kev_used + 2) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); c->kev.push_back(ev); }
-                            HIP_TRY(hipEventRecord(c->kev[kev_used], s_ext));
+                            HIP_TRY(hipEventRecord(c->kev[kev_used], sp));
                         }
-                        launch_extend(s_ext, sd, half[h], c->moving, count, retire_min, leaf_min, wstats);
-                        if (time_kernels) { HIP_TRY(hipEventRecord(c->kev[kev_used + 1], s_ext)); kev_used += 2; }
-                        if (n_half == 2 && !free_run) { HIP_TRY(hipEventRecord(c->ev_ext[h], s_ext)); HIP_TRY(hipStreamWaitEvent(s_shd, c->ev_ext[h], 0)); }
+                        launch_extend(sp, sd, part[h], c->moving, count, retire_min, leaf_min, wstats);
+                        if (time_kernels) { HIP_TRY(hipEventRecord(c->kev[kev_used + 1], sp)); kev_used += 2; }
                         bd.alive_flag = it + 1 == kChunk ? flags + h * 1024 : nullptr;  // only the chunk's last round reports
-                        launch_shade(s_shd, sd, half[h], bd, c->cam, c->moving, count, wstats);
-                        if (n_half == 2 && !free_run) HIP_TRY(hipEventRecord(c->ev_shd[h], s_shd));
+                        launch_shade(sp, sd, part[h], bd, c->cam, c->moving, count, wstats);
                     }
                 }
                 st.iterations += kChunk;
                 HIP_TRY(hipGetLastError());
-                if (n_half == 2) { HIP_TRY(hipEventRecord(c->ev_join, s_shd0)); HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0)); }
+                for (uint32_t h = 1; h < n_parts; h++) { HIP_TRY(hipEventRecord(c->ev_join[h - 1], part_stream[h])); HIP_TRY(hipStreamWaitEvent(s, c->ev_join[h - 1], 0)); }
                 HIP_TRY(hipMemcpyAsync(c->h_flags, flags, kFlagWords * 4, hipMemcpyDeviceToHost, s));
                 HIP_TRY(hipStreamSynchronize(s));
                 uint32_t any = 0;

@@ -301,10 +301,13 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
     uint32_t d_desc_iters = 0, d_desc_lanes = 0, d_leaf_iters = 0, d_leaf_lanes = 0, d_retires = 0, d_retire_lanes = 0;  // COUNT only
     // the lane's column of the live-slot list, read up front so that no ray load ever waits for a list load
     static_assert(kWaveSlots == 256, "four list entries per lane");
-    const uint32_t q0 = lane < count ? P.queue[base + lane] : 0u;
-    const uint32_t q1 = lane + 64u < count ? P.queue[base + lane + 64u] : 0u;
-    const uint32_t q2 = lane + 128u < count ? P.queue[base + lane + 128u] : 0u;
-    const uint32_t q3 = lane + 192u < count ? P.queue[base + lane + 192u] : 0u;
+    uint32_t q0 = base + lane, q1 = q0 + 64u, q2 = q0 + 128u, q3 = q0 + 192u;  // a full list is every slot of the wave, in order
+    if (count != kWaveSlots) {
+        q0 = lane < count ? P.queue[base + lane] : 0u;
+        q1 = lane + 64u < count ? P.queue[base + lane + 64u] : 0u;
+        q2 = lane + 128u < count ? P.queue[base + lane + 128u] : 0u;
+        q3 = lane + 192u < count ? P.queue[base + lane + 192u] : 0u;
+    }
     uint32_t slot = 0;
     bool has = false;
     uint32_t head = 0;  // first list position not handed out yet (wave-uniform)
@@ -707,7 +710,11 @@ __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads) void k
         uint32_t dep[4];
         uint4 rg[4];
 #pragma unroll
-        for (uint32_t t = 0; t < 4u; t++) sq[t] = lane + 64u * t < count ? P.queue[base + lane + 64u * t] : 0u;
+        for (uint32_t t = 0; t < 4u; t++) sq[t] = base + lane + 64u * t;  // a full list is every slot of the wave, in order
+        if (count != kWaveSlots) {
+#pragma unroll
+            for (uint32_t t = 0; t < 4u; t++) sq[t] = lane + 64u * t < count ? P.queue[base + lane + 64u * t] : 0u;
+        }
 #pragma unroll
         for (uint32_t t = 0; t < 4u; t++) {
             h[t] = make_uint2(0u, 0u); dep[t] = 0u; rg[t] = make_uint4(0u, 0u, 0u, 0u);
