@@ -317,6 +317,7 @@ int render_impl(rrt_ctx *c, const rrt_render_params *pp, void *d_rgb8, void *d_a
             const uint32_t nb = std::min(batch, ns_local - s0);
             BatchDev bd{};
             bd.nx = P.nx; bd.ny = P.ny; bd.npix = npix; bd.pixel_map = d_map;
+            bd.div_nx = make_fastdiv(P.nx); bd.div_npix = make_fastdiv(npix);
             bd.n_paths = nb * npix;
             bd.k_first = k_first + s0 * k_step; bd.k_step = k_step;
             bd.seed = P.seed;

@@ -59,9 +59,23 @@ struct PathState {
     uint32_t wave_begin, wave_end;  // the waves (slot stretches) one launch works on
 };
 
+// Division of a 32-bit number by an invariant divisor with one multiply-high (Granlund & Montgomery): for every n,
+// n / d == (t + ((n - t) >> sh1)) >> sh2 with t = high 32 bits of magic * n.
+struct FastDiv { uint32_t magic, sh1, sh2; };
+inline FastDiv make_fastdiv(uint32_t d) {  // d >= 1
+    uint32_t L = 0;
+    while (L < 32 && (uint64_t(1) << L) < d) L++;  // ceil(log2 d)
+    FastDiv f;
+    f.magic = (uint32_t)(((uint64_t(1) << 32) * ((uint64_t(1) << L) - d)) / d + 1);
+    f.sh1 = L < 1 ? L : 1;
+    f.sh2 = L < 1 ? 0 : L - 1;
+    return f;
+}
+
 struct BatchDev {
     uint32_t nx, ny;
     uint32_t npix;             // pixels this call renders
+    FastDiv div_nx, div_npix;
     const uint32_t *pixel_map; // local pixel -> image pixel index (lib.rs:93-94 idx); null = identity
     uint32_t n_paths;          // npix * samples in this batch
     uint32_t k_first, k_step;  // sample index of local sample j is k_first + j * k_step

@@ -80,14 +80,18 @@ DEV void seed_from_u64(Rng &g, uint64_t seed) {
 DEV float4 ray_constants(V3 d) { return make_float4(1.0f / d.x, 1.0f / d.y, 1.0f / d.z, dot3(d, d)); }
 
 // ---- path generation (lib.rs:93-101, camera.rs:56-66) ----
-DEV void generate_path(const BatchDev &Bt, const CameraDev &C, uint32_t p, float4 &A, float4 &B, float4 &K, Rng &g) {
-    const uint32_t sl = p / Bt.npix;
+DEV uint32_t fd_div(uint32_t n, const FastDiv &f) { const uint32_t t = __umulhi(f.magic, n); return (t + ((n - t) >> f.sh1)) >> f.sh2; }
+
+// Leaves 1/direction and direction.direction (ray_constants) to the caller.
+DEV void generate_path(const BatchDev &Bt, const CameraDev &C, uint32_t p, float4 &A, float4 &B, Rng &g) {
+    const uint32_t sl = fd_div(p, Bt.div_npix);
     const uint32_t pl = p - sl * Bt.npix;
     const uint32_t idx = Bt.pixel_map ? Bt.pixel_map[pl] : pl;
     const uint32_t k = Bt.k_first + sl * Bt.k_step;
     seed_from_u64(g, Bt.seed ^ ((uint64_t)idx * 0x9E3779B97F4A7C15ull + (uint64_t)k * 0xD1B54A32D192ED03ull));
-    const float x = (float)(idx % Bt.nx);
-    const float y = (float)(Bt.ny - 1u - idx / Bt.nx);
+    const uint32_t row = fd_div(idx, Bt.div_nx);
+    const float x = (float)(idx - row * Bt.nx);
+    const float y = (float)(Bt.ny - 1u - row);
     const float s = (x + gen_f32(g)) / (float)Bt.nx;
     const float t = (y + gen_f32(g)) / (float)Bt.ny;
     float dx, dy;
@@ -105,7 +109,6 @@ DEV void generate_path(const BatchDev &Bt, const CameraDev &C, uint32_t p, float
     const float time = tv * C.time_scale + C.time_low;  // rand Uniform::sample (camera.rs:64)
     A = make_float4(origin.x, origin.y, origin.z, time);
     B = make_float4(dir.x, dir.y, dir.z, u2f(p));
-    K = ray_constants(dir);
 }
 
 // ---- BVH traversal (acceleration.rs:221-272) over the linked layouts of scene_layout.h ----
@@ -418,12 +421,12 @@ DEV uint64_t path_of_claim(const BatchDev &Bt, uint32_t shard, uint32_t n) { ret
 DEV bool start_path(const PathState &P, const BatchDev &Bt, const CameraDev &C, uint32_t shard, uint32_t n, uint32_t slot) {
     const uint64_t p64 = path_of_claim(Bt, shard, n);
     if (p64 >= (uint64_t)Bt.n_paths) return false;
-    float4 A, B, K;
+    float4 A, B;
     Rng g;
-    generate_path(Bt, C, (uint32_t)p64, A, B, K, g);
+    generate_path(Bt, C, (uint32_t)p64, A, B, g);
     P.rayA[slot] = A;
     P.rayB[slot] = B;
-    P.rayC[slot] = K;
+    P.rayC[slot] = ray_constants(mk(B.x, B.y, B.z));
     P.rng[slot] = make_uint4(g.s0, g.s1, g.s2, g.s3);
     P.depth[slot] = 0u;
     return true;
@@ -526,7 +529,7 @@ DEV void shade_slot(const SceneDev &S, const Tables &T, const PathState &P, cons
     const float time = A.w;
     float rx = 0.0f, ry = 0.0f, rz = 0.0f;  // radiance of a finished path
     // what the slot holds afterwards
-    float4 oA = A, oB = B, oC = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 oA = A, oB = B;
     Rng g;
     g.s0 = gw.x; g.s1 = gw.y; g.s2 = gw.z; g.s3 = gw.w;
     uint32_t o_depth = 0u;
@@ -629,7 +632,6 @@ DEV void shade_slot(const SceneDev &S, const Tables &T, const PathState &P, cons
         if (scattered) {
             oA = make_float4(p.x, p.y, p.z, time);
             oB = make_float4(dir.x, dir.y, dir.z, B.w);
-            oC = ray_constants(dir);
             const bool on_trail = cls != CL_DIEL;
             o_depth = (depth + 1u) | ((trail_len + (on_trail ? 1u : 0u)) << 16);
             if (on_trail) {
@@ -648,7 +650,7 @@ DEV void shade_slot(const SceneDev &S, const Tables &T, const PathState &P, cons
     if (ended) {
         const uint64_t p64 = path_of_claim(Bt, shard, next_n);
         if (p64 < (uint64_t)Bt.n_paths) {
-            generate_path(Bt, C, (uint32_t)p64, oA, oB, oC, g);
+            generate_path(Bt, C, (uint32_t)p64, oA, oB, g);
             o_depth = 0u;
             alive = true;
             started = true;
@@ -657,7 +659,7 @@ DEV void shade_slot(const SceneDev &S, const Tables &T, const PathState &P, cons
     if (alive) {
         P.rayA[slot] = oA;
         P.rayB[slot] = oB;
-        P.rayC[slot] = oC;
+        P.rayC[slot] = ray_constants(mk(oB.x, oB.y, oB.z));  // once for scattered and new rays alike
         P.rng[slot] = make_uint4(g.s0, g.s1, g.s2, g.s3);
         P.depth[slot] = o_depth;
         P.recent[slot] = o_recent;  // also where nothing changed: a store that covers whole lines costs the memory system less than a sparse one
