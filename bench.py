@@ -43,7 +43,7 @@ def extend_bytes(st):
     return 60 * st["rays"]
 
 
-def cpu_baseline(ns_sample=16):
+def cpu_baseline(ns_sample=200):
     from oracle import MODE_REF_POOL, OracleScene
 
     threads = min(16, os.cpu_count() or 1)
@@ -152,6 +152,10 @@ def main():
     roofline = None
     if not args.no_roofline:
         cst = step(count=True)  # every rank takes part (the pass ends in the same reduce); rank 0 reports its own counters
+        # one more step with the path pool in one part on one stream: extend launches that overlap nothing
+        os.environ["RRT_STREAMS"] = "1"
+        ist = step(timed=True)
+        del os.environ["RRT_STREAMS"]
         if rank == 0 and ext_ms > 0:
             flops = extend_flops(cst) * args.steps
             byts = extend_bytes(cst) * args.steps
@@ -168,7 +172,12 @@ def main():
                 "launches": ext_launches, "avg_launch_ms": round(ext_ms / max(1, ext_launches), 4),
                 "flop_per_launch": round(flops / max(1, ext_launches)),
                 "note": "extend launches of the two halves of the path pool run on two streams and overlap each other and the shade "
-                        "kernel, so the summed launch durations exceed wall time and `achieved` is a lower bound",
+                        "kernel, so the summed launch durations exceed wall time and `achieved` is a lower bound; `isolated` is the "
+                        "same kernel on the whole pool with nothing beside it (one extra step on one stream)",
+                "isolated": {"achieved": round(extend_flops(cst) / (ist["extend_ms"] * 1e-3) / 1e12, 3),
+                             "frac": round(extend_flops(cst) / (ist["extend_ms"] * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 4),
+                             "launches": ist["extend_launches"], "avg_launch_ms": round(ist["extend_ms"] / max(1, ist["extend_launches"]), 4),
+                             "step_ms": round(ist["gpu_ms"], 2)},
                 "hbm": {"achieved": round(byts / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(byts / sec / 1e9 / HBM_PEAK_GBS, 4)},
                 "per_ray": {"inner_visits": round(cst["inner_visits"] / cst["rays"], 2), "leaf_tests": round(cst["leaf_tests"] / cst["rays"], 2),
                             "rays_per_path": round(cst["rays"] / cst["paths"], 3)},
