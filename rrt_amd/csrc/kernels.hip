@@ -304,7 +304,7 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
     uint32_t d_desc_iters = 0, d_desc_lanes = 0, d_leaf_iters = 0, d_leaf_lanes = 0, d_retires = 0, d_retire_lanes = 0;  // COUNT only
     // the lane's column of the live-slot list, read up front so that no ray load ever waits for a list load
     static_assert(kWaveSlots == 256, "four list entries per lane");
-    uint32_t q0 = base + lane, q1 = q0 + 64u, q2 = q0 + 128u, q3 = q0 + 192u;  // a full list is every slot of the wave, in order
+    uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;
     if (count != kWaveSlots) {
         q0 = lane < count ? P.queue[base + lane] : 0u;
         q1 = lane + 64u < count ? P.queue[base + lane + 64u] : 0u;
@@ -326,13 +326,14 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
             if (COUNT) { d_retires++; d_retire_lanes += (uint32_t)__popcll(ready); }
             // every idle lane takes the next ray of the list, in lane order; list entry p sits in lane p % 64, register p / 64
             const uint32_t pos = head + (uint32_t)__popcll(idle_m & lt_mask);
-            const uint32_t col = pos >> 6;
-            const uint32_t q_sel = col == 0u ? q0 : (col == 1u ? q1 : (col == 2u ? q2 : q3));
-            (void)q_sel;
-            const int src = (int)(pos & 63u);
-            const uint32_t s0 = (uint32_t)__shfl((int)q0, src, 64), s1 = (uint32_t)__shfl((int)q1, src, 64);
-            const uint32_t s2 = (uint32_t)__shfl((int)q2, src, 64), s3 = (uint32_t)__shfl((int)q3, src, 64);
-            const uint32_t n_slot = col == 0u ? s0 : (col == 1u ? s1 : (col == 2u ? s2 : s3));
+            uint32_t n_slot = base + pos;  // a full list is every slot of the wave, in order
+            if (count != kWaveSlots) {
+                const uint32_t col = pos >> 6;
+                const int src = (int)(pos & 63u);
+                const uint32_t s0 = (uint32_t)__shfl((int)q0, src, 64), s1 = (uint32_t)__shfl((int)q1, src, 64);
+                const uint32_t s2 = (uint32_t)__shfl((int)q2, src, 64), s3 = (uint32_t)__shfl((int)q3, src, 64);
+                n_slot = col == 0u ? s0 : (col == 1u ? s1 : (col == 2u ? s2 : s3));
+            }
             const bool take = idle && pos < count;
             float4 nA = make_float4(0, 0, 0, 0), nB = nA, nC = nA;
             if (take) { nA = P.rayA[n_slot]; nB = P.rayB[n_slot]; nC = P.rayC[n_slot]; }
@@ -667,7 +668,10 @@ DEV void shade_slot(const SceneDev &S, const Tables &T, const PathState &P, cons
 }
 
 template <bool MOVING, bool COUNT, bool TABLES>
-__global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads) void k_shade(SceneDev S, PathState P, BatchDev Bt, CameraDev C,
+#ifndef RRT_SHADE_WAVES
+#define RRT_SHADE_WAVES 1
+#endif
+__global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads, RRT_SHADE_WAVES) void k_shade(SceneDev S, PathState P, BatchDev Bt, CameraDev C,
                                                                                       uint64_t *wave_stats) {
     constexpr uint32_t kThreads = TABLES ? kShadeTableThreads : kBlockThreads;
     extern __shared__ uint4 lds4[];  // per wave kShadeLdsWords words, then (TABLES) the sphere and material tables
