@@ -37,22 +37,35 @@ def extend_flops(st):
     return 22 * st["inner_visits"] + 39 * st["leaf_tests"]
 
 
+def job_flops(st):
+    """Algorithmic FLOPs of the whole path: 3 divides for 1/d and 3 multiplies of the attenuation product per ray, box and
+    sphere tests, hit record, scatter per material, sky, ray generation (fma = 2, min/max/compare = 1, integer work and
+    selects not counted)."""
+    hits = st["hits_lambertian"] + st["hits_metal"] + st["hits_dielectric"]
+    return (6 * st["rays"] + 22 * st["inner_visits"] + 39 * st["leaf_tests"] + 20 * hits + 34 * st["hits_lambertian"]
+            + 54 * st["hits_metal"] + 45 * st["hits_dielectric"] + 22 * st["sky_misses"] + 45 * st["paths"])
+
+
 def extend_bytes(st):
     """Algorithmic bytes the extend kernel moves to and from HBM: per ray 48 B of ray state + 4 B list entry in, 8 B hit
     out.  (The BVH — 32 B per box test, 16 B per sphere test — is read from the LDS copy, not from HBM.)"""
     return 60 * st["rays"]
 
 
-def cpu_baseline(ns_sample=200):
+def cpu_baseline(ns_sample=200, ns_one_core=8):
     from oracle import MODE_REF_POOL, OracleScene
 
     threads = min(16, os.cpu_count() or 1)
     osc = OracleScene.build(1, NX, NY, seed=SEED)
     state = osc.rng_after()
     t0 = time.perf_counter()
+    _, _, ctr1 = osc.render(NX, NY, ns_one_core, seed=SEED, mode=MODE_REF_POOL, threads=1, state=state, pow5_mode=1)
+    dt1 = time.perf_counter() - t0
+    t0 = time.perf_counter()
     _, _, ctr = osc.render(NX, NY, ns_sample, seed=SEED, mode=MODE_REF_POOL, threads=threads, state=state, pow5_mode=1)
     dt = time.perf_counter() - t0
     return {"value": round(ctr["rays"] / dt / 1e6, 2), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "one_core": {"value": round(ctr1["rays"] / dt1 / 1e6, 2), "unit": "Mrays/s", "sample": f"{ns_one_core} spp, {ctr1['rays']} rays in {dt1:.2f} s"},
             "sample": f"chap12 {NX}x{NY}, {ns_sample} of {NS} spp, depth {MAX_DEPTH}, seed {SEED}: {ctr['rays']} rays in {dt:.2f} s; "
                       "C restatement of the reference CPU path (recursive trace, per-thread jumped Xoshiro128+, pixels claimed "
                       "dynamically, libm powf), scene build excluded; the Rust reference itself cannot be built here"}
@@ -178,6 +191,9 @@ def main():
                              "frac": round(extend_flops(cst) / (ist["extend_ms"] * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 4),
                              "launches": ist["extend_launches"], "avg_launch_ms": round(ist["extend_ms"] / max(1, ist["extend_launches"]), 4),
                              "step_ms": round(ist["gpu_ms"], 2)},
+                "whole_job": {"achieved": round(job_flops(cst) * args.steps / elapsed / 1e12, 3), "unit": "TFLOP/s",
+                              "frac": round(job_flops(cst) * args.steps / elapsed / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 4),
+                              "note": "all algorithmic FLOPs of a step (every kernel) over wall time"},
                 "hbm": {"achieved": round(byts / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(byts / sec / 1e9 / HBM_PEAK_GBS, 4)},
                 "per_ray": {"inner_visits": round(cst["inner_visits"] / cst["rays"], 2), "leaf_tests": round(cst["leaf_tests"] / cst["rays"], 2),
                             "rays_per_path": round(cst["rays"] / cst["paths"], 3)},

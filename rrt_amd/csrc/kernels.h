@@ -35,8 +35,8 @@ struct SceneDev {
     float u_time0, u_dt;
     // compact copy for LDS residency (null when the scene does not qualify; see scene_layout.h)
     const uint4 *small_nodes;
-    uint32_t small_words;   // 12 or 16 words per node
-    uint32_t small_root;    // 16-bit reference of the root
+    uint32_t small_words;   // words per node
+    uint32_t small_root;    // reference of the root
     uint32_t n_nodes;
     uint32_t n_spheres;
 };

@@ -122,7 +122,9 @@ struct RayCtx {
     float time, f_ray;
     float tmin, tmax;
     uint32_t oct;   // bit k set: 1/d[k] < 0 (acceleration.rs:230-231)
-    uint32_t sgn;   // the same three bits at positions 4, 12 and 20: (sgn >> 8 * axis) & 0x1F is 16 if the ray is negative along axis
+    // for the compact LDS nodes: byte offset inside a node of the (near, far) plane pair of each axis, and a word whose
+    // 5-bit field at 5 * axis (repeated 16 bits up) is the bit position of the near child's reference in node word 9
+    uint32_t cx, cy, cz, sel;
     uint32_t best;  // store-specific handle of the closest leaf so far
 };
 
@@ -131,7 +133,9 @@ DEV V3 origin(const RayCtx &r) { return mk(r.ox.x, r.oy.x, r.oz.x); }
 DEV void ray_finish(RayCtx &r, float tmin, float tmax, const SceneDev &S, bool uniform_times) {
     const uint32_t nx = r.ox.y < 0.0f ? 1u : 0u, ny = r.oy.y < 0.0f ? 1u : 0u, nz = r.oz.y < 0.0f ? 1u : 0u;  // acceleration.rs:230-231
     r.oct = nx | (ny << 1) | (nz << 2);
-    r.sgn = (nx << 4) | (ny << 12) | (nz << 20);
+    r.cx = nx << 2; r.cy = 12u + (ny << 2); r.cz = 24u + (nz << 2);
+    const uint32_t sel15 = (nx ? 4u + kRef14Bits : 4u) | ((ny ? 4u + kRef14Bits : 4u) << 5) | ((nz ? 4u + kRef14Bits : 4u) << 10);
+    r.sel = sel15 | (sel15 << 16);
     r.f_ray = uniform_times ? (r.time - S.u_time0) / S.u_dt : 0.0f;  // center_at's factor when every moving sphere shares its shutter interval
     r.tmin = tmin;
     r.tmax = tmax;
@@ -161,12 +165,17 @@ struct HbmStore {
     DEV explicit HbmStore(const SceneDev &s) : S(s) {}
     DEV uint32_t root() const { return S.root_ref; }
     DEV bool uniform_times() const { return MOVING && (S.flags & kSceneUniformTimes); }
-    DEV void inner(uint32_t cur, uint32_t oct, uint32_t, f32x2 &bx, f32x2 &by, f32x2 &bz, uint32_t &near_ref, uint32_t &exit_ref) const {
+    // bx, by, bz: per axis the (near, far) planes of the node's box for this ray (acceleration.rs:66-71)
+    DEV void inner(uint32_t cur, const RayCtx &r, f32x2 &bx, f32x2 &by, f32x2 &bz, uint32_t &near_ref, uint32_t &exit_ref) const {
+        const uint32_t oct = r.oct;
         const uint32_t idx = cur & kRefIndexMask;
         const uint4 n0 = S.nodes[idx * 4u];
         const uint4 n1 = S.nodes[idx * 4u + 1u];
         exit_ref = reinterpret_cast<const uint32_t *>(S.nodes)[idx * kNodeWords + 8u + oct];
-        bx = f32x2{u2f(n0.x), u2f(n0.y)}; by = f32x2{u2f(n0.z), u2f(n0.w)}; bz = f32x2{u2f(n1.x), u2f(n1.y)};
+        const bool ngx = oct & 1u, ngy = oct & 2u, ngz = oct & 4u;
+        bx = ngx ? f32x2{u2f(n0.y), u2f(n0.x)} : f32x2{u2f(n0.x), u2f(n0.y)};
+        by = ngy ? f32x2{u2f(n0.w), u2f(n0.z)} : f32x2{u2f(n0.z), u2f(n0.w)};
+        bz = ngz ? f32x2{u2f(n1.y), u2f(n1.x)} : f32x2{u2f(n1.x), u2f(n1.y)};
         const uint32_t axis = (n1.z >> RRT_NODE_AXIS_SHIFT) & 3u;
         near_ref = ((oct >> axis) & 1u) ? (n1.z & (kRefLeafBit | kRefIndexMask)) : n1.w;  // acceleration.rs:253-267
     }
@@ -190,43 +199,45 @@ struct HbmStore {
 
 template <bool MOVING>
 struct LdsStore {
-    static constexpr uint32_t kEnd = kRef16End;
-    static constexpr uint32_t W = MOVING ? kSmallWordsMoving : kSmallWordsStatic;
-    const uint4 *v4;
-    uint32_t root16;
-    DEV LdsStore(const uint4 *p, uint32_t r) : v4(p), root16(r) {}
-    DEV uint32_t root() const { return root16; }
+    static constexpr uint32_t kEnd = kRef14End;
+    const char *lds;
+    uint32_t root14;
+    DEV LdsStore(const void *p, uint32_t r) : lds(static_cast<const char *>(p)), root14(r) {}
+    DEV uint32_t root() const { return root14; }
     DEV bool uniform_times() const { return MOVING; }  // the compact copy exists only for scenes with one shutter interval
-    // a reference is the node's offset in 16-byte units (bit 15: leaf)
-    DEV const char *node_at(uint32_t off16) const { return reinterpret_cast<const char *>(v4) + (off16 << 4); }
-    DEV void inner(uint32_t cur, uint32_t oct, uint32_t sgn, f32x2 &bx, f32x2 &by, f32x2 &bz, uint32_t &near_ref, uint32_t &exit_ref) const {
-        const char *node = node_at(cur);
-        const uint4 n0 = *reinterpret_cast<const uint4 *>(node);
-        const uint4 n1 = *reinterpret_cast<const uint4 *>(node + 16);
-        exit_ref = *reinterpret_cast<const uint16_t *>(node + 32u + 2u * oct);
-        bx = f32x2{u2f(n0.x), u2f(n0.y)}; by = f32x2{u2f(n0.z), u2f(n0.w)}; bz = f32x2{u2f(n1.x), u2f(n1.y)};
-        near_ref = (n1.z >> ((sgn >> n1.w) & 0x1Fu)) & 0xFFFFu;  // left in the low half, right in the high half; n1.w = 8 * axis
+    // a reference is the node's offset in 8-byte units (bit 13: leaf)
+    DEV const char *node_at(uint32_t off8) const { return lds + (off8 << 3); }
+    DEV static f32x2 pair_at(const char *p) { const float *f = reinterpret_cast<const float *>(p); return f32x2{f[0], f[1]}; }
+    // The box is stored per axis as (min, max, min): the pair that starts one word in is (max, min), so a ray that is
+    // negative along the axis reads (near, far) directly, with an address instead of a select.
+    DEV void inner(uint32_t cur, const RayCtx &r, f32x2 &bx, f32x2 &by, f32x2 &bz, uint32_t &near_ref, uint32_t &exit_ref) const {
+        const uint32_t off = cur << 3;
+        bx = pair_at(lds + (off + r.cx)); by = pair_at(lds + (off + r.cy)); bz = pair_at(lds + (off + r.cz));
+        const uint32_t w9 = *reinterpret_cast<const uint32_t *>(lds + off + 36u);
+        exit_ref = *reinterpret_cast<const uint16_t *>(lds + (off + 2u * r.oct) + 40u);
+        // word 9 = 5 * axis | left << 4 | right << 18; only the low five bits of a shift count (v_bfe_u32) count
+        const uint32_t at = __builtin_amdgcn_ubfe(r.sel, w9, 5u);
+        near_ref = __builtin_amdgcn_ubfe(w9, at, kRef14Bits);
     }
     DEV void leaf(uint32_t cur, const RayCtx &r, V3 &c, float &rr, uint32_t &handle, uint32_t &exit_ref) const {
-        const uint32_t off16 = cur & (kRef16LeafBit - 1u);
-        const char *node = node_at(off16);
-        const uint4 n0 = *reinterpret_cast<const uint4 *>(node);
-        exit_ref = *reinterpret_cast<const uint16_t *>(node + 32u + 2u * r.oct);
-        c = mk(u2f(n0.x), u2f(n0.y), u2f(n0.z));
-        rr = u2f(n0.w);
-        handle = off16;
+        const uint32_t off8 = cur & (kRef14LeafBit - 1u);
+        const char *node = node_at(off8);
+        const uint2 n0 = *reinterpret_cast<const uint2 *>(node), n1 = *reinterpret_cast<const uint2 *>(node + 8);
+        exit_ref = *reinterpret_cast<const uint16_t *>(node + 40u + 2u * r.oct);
+        c = mk(u2f(n0.x), u2f(n0.y), u2f(n1.x));
+        rr = u2f(n1.y);
+        handle = off8;
         if (MOVING) {
-            const uint4 m = *reinterpret_cast<const uint4 *>(node + 48);  // centre1 - centre0, zero words for a sphere at rest
-            if (*reinterpret_cast<const uint32_t *>(node + 20) & 1u) c = add(c, scale(r.f_ray, mk(u2f(m.x), u2f(m.y), u2f(m.z))));
+            const float *m = reinterpret_cast<const float *>(node + 24);  // centre1 - centre0, zero words for a sphere at rest
+            if (*reinterpret_cast<const uint32_t *>(node + 20) & 1u) c = add(c, scale(r.f_ray, mk(m[0], m[1], m[2])));
         }
     }
     DEV uint32_t prim_of(uint32_t handle) const { return *reinterpret_cast<const uint32_t *>(node_at(handle) + 16); }
 };
 
 // Aabb::intersect (acceleration.rs:60-84) against the current t_max, then the step of acceleration.rs:250-267.
-// Node boxes are stored as (min, max) pairs per axis, so both planes of an axis go through one packed subtract and
-// one packed multiply; which of the two results is "near" is chosen afterwards by the sign of 1/d, which selects
-// the same operands the reference's blend selects before its arithmetic.
+// The node store hands out, per axis, the (near, far) planes the reference's blend selects by the sign of 1/d; both go
+// through one packed subtract and one packed multiply.
 // (box - origin) * (1 / direction) for both planes of one axis.  `oi` is {origin, 1 / direction}: the subtract reads its
 // low half for both results and the multiply its high half, so the ray needs no duplicated operands in registers.
 DEV f32x2 slab_pair(f32x2 box, f32x2 oi) {
@@ -240,11 +251,10 @@ template <class Store>
 DEV uint32_t visit_inner(const Store &st, uint32_t cur, const RayCtx &r) {
     f32x2 bx, by, bz;
     uint32_t near_ref, exit_ref;
-    st.inner(cur, r.oct, r.sgn, bx, by, bz, near_ref, exit_ref);
+    st.inner(cur, r, bx, by, bz, near_ref, exit_ref);
     const f32x2 tx = slab_pair(bx, r.ox), ty = slab_pair(by, r.oy), tz = slab_pair(bz, r.oz);
-    const bool ngx = r.oct & 1u, ngy = r.oct & 2u, ngz = r.oct & 4u;
-    const float tnx = ngx ? tx.y : tx.x, tny = ngy ? ty.y : ty.x, tnz = ngz ? tz.y : tz.x;
-    const float tfx = ngx ? tx.x : tx.y, tfy = ngy ? ty.x : ty.y, tfz = ngz ? tz.x : tz.y;
+    const float tnx = tx.x, tny = ty.x, tnz = tz.x;
+    const float tfx = tx.y, tfy = ty.y, tfz = tz.y;
     // each far value is scaled by 1 + 2*gamma(3) (acceleration.rs:60-84); rounding x -> x * k is monotonic, so scaling
     // the smallest of the three gives bit for bit the smallest of the three scaled values.  The min/max chains are
     // spelled as instructions because the compiler cannot know that the packed results above are already canonical
@@ -397,8 +407,9 @@ template <bool MOVING, bool COUNT>
 __global__ __launch_bounds__(kLdsBlockThreads, 8) void k_extend_lds(SceneDev S, PathState P, uint32_t retire_min, uint32_t leaf_min,
                                                                   uint64_t *wave_stats) {
     extern __shared__ uint4 lds4[];
-    const uint32_t n_vec = S.n_nodes * (LdsStore<MOVING>::W / 4u);
-    for (uint32_t i = threadIdx.x; i < n_vec; i += kLdsBlockThreads) lds4[i] = S.small_nodes[i];
+    const uint32_t n_vec = S.n_nodes * (kSmallWords / 2u);
+    for (uint32_t i = threadIdx.x; i < n_vec; i += kLdsBlockThreads)
+        reinterpret_cast<uint2 *>(lds4)[i] = reinterpret_cast<const uint2 *>(S.small_nodes)[i];
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = P.wave_begin + ((blockIdx.x * kLdsBlockThreads + threadIdx.x) >> 6);

@@ -140,32 +140,34 @@ int build_scene_layout(const rrt_sphere_soa *sp, const rrt_material_soa *mt, con
         }
     }
 
-    // ---- compact copy for LDS residency: 48 or 64 bytes per node; a 16-bit reference is the node's offset in 16-byte
-    //      units (so a shift makes the LDS address), bit 15 marks a leaf ----
+    // ---- compact copy for LDS residency (layout in scene_layout.h) ----
     const bool moving = (out.flags & kSceneHasMoving) != 0;
-    const uint32_t sw = moving ? kSmallWordsMoving : kSmallWordsStatic;
+    const uint32_t sw = kSmallWords;
     const bool times_ok = !moving || (out.flags & kSceneUniformTimes) != 0;
-    if (times_ok && static_cast<size_t>(n_nodes) * sw * 4 <= kSmallLdsBudget) {
-        auto ref16 = [&](uint32_t r) -> uint32_t {
-            if (r == kRefEnd) return kRef16End;
-            return (r & kRefIndexMask) * (sw / 4u) | ((r & kRefLeafBit) ? kRef16LeafBit : 0u);
+    if (times_ok && static_cast<size_t>(n_nodes) * (sw / 2u) < kRef14End && static_cast<size_t>(n_nodes) * sw * 4 <= kSmallLdsBudget) {
+        auto ref14 = [&](uint32_t r) -> uint32_t {
+            if (r == kRefEnd) return kRef14End;
+            return (r & kRefIndexMask) * (sw / 2u) | ((r & kRefLeafBit) ? kRef14LeafBit : 0u);
         };
         out.small_words = sw;
         out.small_nodes.assign(static_cast<size_t>(n_nodes) * sw, 0u);
         for (uint32_t i = 0; i < n_nodes; i++) {
             const uint32_t *w = &out.nodes[static_cast<size_t>(i) * kNodeWords];
             uint32_t *s = &out.small_nodes[static_cast<size_t>(i) * sw];
-            for (int k = 0; k < 6; k++) s[k] = w[k];
             if (!is_leaf(nodes[i])) {
-                s[6] = ref16(w[7]) | (ref16(w[6] & (kRefLeafBit | kRefIndexMask)) << 16);
-                s[7] = ((w[6] >> RRT_NODE_AXIS_SHIFT) & 3u) * 8u;  // bit offset of the axis' field in the ray's sign word
-            } else if (moving && (w[5] & 1u)) {
-                const Float4 &m = out.motion[w[4] & kLeafPrimMask];
-                s[12] = f2u(m.x); s[13] = f2u(m.y); s[14] = f2u(m.z);
+                for (int k = 0; k < 3; k++) { s[3 * k] = w[2 * k]; s[3 * k + 1] = w[2 * k + 1]; s[3 * k + 2] = w[2 * k]; }
+                const uint32_t axis = (w[6] >> RRT_NODE_AXIS_SHIFT) & 3u;
+                s[9] = axis * 5u | (ref14(w[7]) << 4) | (ref14(w[6] & (kRefLeafBit | kRefIndexMask)) << (4 + kRef14Bits));
+            } else {
+                for (int k = 0; k < 6; k++) s[k] = w[k];
+                if (moving && (w[5] & 1u)) {
+                    const Float4 &m = out.motion[w[4] & kLeafPrimMask];
+                    s[6] = f2u(m.x); s[7] = f2u(m.y); s[8] = f2u(m.z);
+                }
             }
-            for (int o = 0; o < 8; o += 2) s[8 + o / 2] = ref16(w[8 + o]) | (ref16(w[8 + o + 1]) << 16);
+            for (int o = 0; o < 8; o += 2) s[10 + o / 2] = ref14(w[8 + o]) | (ref14(w[8 + o + 1]) << 16);
         }
-        out.small_root = ref16(out.root_ref);
+        out.small_root = ref14(out.root_ref);
     }
     return RRT_OK;
 }

@@ -22,12 +22,12 @@ constexpr uint32_t kNodeWords = 16;             // 64 bytes
 constexpr uint32_t kLeafPrimMask = 0x3FFFFFFFu; // leaf word 4: sphere index | material kind << 30
 constexpr uint32_t kLeafKindShift = 30;
 
-// Compact layout for scenes small enough to live in a workgroup's LDS.  A 16-bit reference is the node's offset in
-// 16-byte units (at most 4095 inside the 64 KB budget) with bit 15 set for a leaf.
-constexpr uint32_t kRef16LeafBit = 0x8000u;
-constexpr uint32_t kRef16End = 0x7FFFu;
-constexpr uint32_t kSmallWordsStatic = 12;   // 48 bytes per node
-constexpr uint32_t kSmallWordsMoving = 16;   // 64 bytes per node: + centre1 - centre0
+// Compact layout for scenes small enough to live in a workgroup's LDS: 56-byte nodes.  A 14-bit reference is the
+// node's offset in 8-byte units with bit 13 set for a leaf.
+constexpr uint32_t kRef14LeafBit = 0x2000u;
+constexpr uint32_t kRef14End = 0x1FFFu;
+constexpr uint32_t kRef14Bits = 14;
+constexpr uint32_t kSmallWords = 14;
 constexpr uint32_t kSmallLdsBudget = 64u * 1024u;
 
 // Per-sphere info word: material index | kind << 28 | moving << 31
@@ -50,12 +50,15 @@ struct SceneLayout {
     uint32_t root_ref = kRefEnd;
     uint32_t max_leaf_depth = 0;
 
-    // Compact node words (empty when the scene does not qualify).  [0..5] inner: (min, max) per axis; leaf: centre,
-    // radius^2, sphere index, moving flag.  [6] inner: left ref16 | right
-    // ref16 << 16.  [7] inner: 8 * axis.  [8..11] eight 16-bit exit links.  [12..14] (moving scenes) centre1 - centre0.
+    // Compact node words (empty when the scene does not qualify).
+    // Inner: [0..8] per axis (min, max, min), so that the two words starting at 3 * axis + s are (near, far) for a ray
+    //        whose direction is negative (s = 1) or not (s = 0) along that axis; [9] 5 * axis | left ref << 4 |
+    //        right ref << 18; [10..13] eight 16-bit exit links.
+    // Leaf:  [0..2] centre at time0, [3] radius^2, [4] sphere index | kind << 30, [5] bit 0 = moving,
+    //        [6..8] centre1 - centre0, [10..13] exit links.
     std::vector<uint32_t> small_nodes;
     uint32_t small_words = 0;
-    uint32_t small_root = kRef16End;
+    uint32_t small_root = kRef14End;
 
     std::vector<Float4> sph;        // {centre at time0, radius}
     std::vector<Float4> motion;     // {centre1 - centre0, time0}
