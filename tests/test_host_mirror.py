@@ -140,11 +140,12 @@ def test_exit_links_reproduce_the_stack_order(kind):
         hits = rng.uniform(size=len(nd)) < p
         f = lambda i: bool(hits[i])
         assert linked_visit_order(words, root, oct_, f) == stack_visit_order(nd, oct_, f)
-    # leaf payload: centre, radius^2, sphere index
+    # leaf payload: centre, radius^2, sphere index with the material kind in the top two bits
     leaves = np.nonzero(nd[:, 7] >> 31)[0]
     for i in leaves[:50]:
         obj = int(nd[i, 6])
-        assert words[i, 4] == obj
+        assert int(words[i, 4]) & 0x3FFFFFFF == obj
+        assert int(words[i, 4]) >> 30 == int(mt[mid[obj], 0])
         assert np.array_equal(words[i, 0:3], sp[obj, 0:3].view(np.uint32))
         assert words[i, 3] == np.float32(sp[obj, 8] * sp[obj, 8]).view(np.uint32)
     assert flags == 0
