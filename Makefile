@@ -11,7 +11,9 @@ LIB     := rrt_amd/librrt_amd.so
 OBJDIR  := build
 OBJS    := $(OBJDIR)/kernels.o $(OBJDIR)/capi.o $(OBJDIR)/scene_layout.o $(OBJDIR)/rrt.o $(OBJDIR)/host_capi.o
 
-all: $(LIB) oracle
+CLI     := rrt_amd/rrt
+
+all: $(LIB) $(CLI) oracle
 
 $(OBJDIR):
 	mkdir -p $(OBJDIR)
@@ -33,6 +35,13 @@ $(OBJDIR)/host_capi.o: rrt_amd/host/host_capi.cpp rrt_amd/host/rrt.hpp include/r
 
 $(LIB): $(OBJS)
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJS)
+
+$(OBJDIR)/rrt_cli.o: rrt_amd/host/rrt_cli.cpp rrt_amd/host/rrt.hpp include/rrt_amd.h include/rrt_amd_host.h | $(OBJDIR)
+	$(HIPCC) $(CXXFLAGS) -c $< -o $@
+
+# the C++ mirror is linked in as an object (the library exports only the C ABI)
+$(CLI): $(OBJDIR)/rrt_cli.o $(OBJDIR)/rrt.o $(LIB)
+	$(HIPCC) $(OBJDIR)/rrt_cli.o $(OBJDIR)/rrt.o -o $@ -Lrrt_amd -lrrt_amd -Wl,-rpath,'$$ORIGIN' -lpthread
 
 oracle:
 	$(MAKE) -C oracle

@@ -1,5 +1,7 @@
 """GPU path vs CPU oracle, through the C ABI.  Bit-exact: f32 sums compared as bit patterns, RGB8 equal,
 work counters equal.  Everything here needs an MI355X."""
+import os
+
 import numpy as np
 import pytest
 
@@ -328,3 +330,20 @@ def test_million_sphere_scene_spot(gpu_ctx):
     assert np.array_equal(bits(acc.reshape(-1, 3)[idx]), bits(acc_o))
     assert np.array_equal(rgb.reshape(-1, 3)[idx], rgb_o)
     assert st["paths"] == nx * ny * ns
+
+
+def test_cli_renders_the_reference_default_scene(gpu_ctx, tmp_path):
+    """rrt -r WxH -s N -e SEED (main.rs:12-108): same generator -> scene -> pool -> tracescene sequence as the library path."""
+    import subprocess
+    nx, ny, ns, seed = 64, 40, 4, 5
+    out = tmp_path / "o.ppm"
+    exe = os.path.join(os.path.dirname(os.path.abspath(rrt_amd.__file__)), "rrt")
+    r = subprocess.run([exe, "-r", f"{nx}x{ny}", "-s", str(ns), "-e", str(seed), "-o", str(out)], capture_output=True, text=True, timeout=100)
+    assert r.returncode == 0, r.stderr
+    assert f"Rendering {nx} x {ny} image using {ns} samples per pixel." in r.stderr
+    raw = out.read_bytes()
+    header = f"P6\n{nx} {ny}\n255\n".encode()
+    assert raw.startswith(header) and len(raw) == len(header) + nx * ny * 3
+    hs = rrt_amd.HostScene(rrt_amd.SCENE_BOOK2CHAP2, nx, ny, seed=seed)
+    px, _, _ = hs.tracescene(ns, device=0)
+    assert np.array_equal(np.frombuffer(raw[len(header):], np.uint8).reshape(ny, nx, 3), px)

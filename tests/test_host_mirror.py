@@ -227,3 +227,19 @@ def test_no_gpu_means_a_loud_failure():
         pytest.skip("a GPU is present")
     with pytest.raises(rrt_amd.RrtError, match="no HIP device|HIP"):
         rrt_amd.Context(0)
+
+
+def test_cli_argument_handling():
+    """The flags of main.rs:12-71; these paths return before any device is touched."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(rrt_amd.__file__)), "rrt")
+    r = subprocess.run([exe, "--help"], capture_output=True, text=True, timeout=20)
+    assert r.returncode == 0 and "--resolution" in r.stderr and "--samples" in r.stderr and "--seed" in r.stderr and "--random" in r.stderr
+    r = subprocess.run([exe, "-r", "12y8"], capture_output=True, text=True, timeout=20)
+    assert r.returncode == 0 and "invalid resolution" in r.stderr  # main.rs:49-52: message, then a normal return
+    r = subprocess.run([exe, "-s", "many"], capture_output=True, text=True, timeout=20)
+    assert r.returncode == 0 and "invalid sample count" in r.stderr
+    r = subprocess.run([exe, "-e", "-3"], capture_output=True, text=True, timeout=20)
+    assert r.returncode == 0 and "invalid rng seed" in r.stderr
+    r = subprocess.run([exe, "--bogus"], capture_output=True, text=True, timeout=20)
+    assert r.returncode == 2
