@@ -193,7 +193,7 @@ def main():
                              "step_ms": round(ist["gpu_ms"], 2)},
                 "whole_job": {"achieved": round(job_flops(cst) * args.steps / elapsed / 1e12, 3), "unit": "TFLOP/s",
                               "frac": round(job_flops(cst) * args.steps / elapsed / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 4),
-                              "note": "all algorithmic FLOPs of a step (every kernel) over wall time"},
+                              "note": "all algorithmic FLOPs of a step (every kernel) over wall time, per GPU (rank 0's share)"},
                 "hbm": {"achieved": round(byts / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(byts / sec / 1e9 / HBM_PEAK_GBS, 4)},
                 "per_ray": {"inner_visits": round(cst["inner_visits"] / cst["rays"], 2), "leaf_tests": round(cst["leaf_tests"] / cst["rays"], 2),
                             "rays_per_path": round(cst["rays"] / cst["paths"], 3)},

@@ -719,7 +719,7 @@ __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads, RRT_SH
     // ---- 1. classify ----
     uint32_t sq[4];        // the slots at list positions lane + 64 t
     uint32_t classes = 0;  // class of each of them, 4 bits apiece
-    uint32_t end_rank[4];  // position of a slot among the wave's ending paths (sky, depth limit)
+    uint32_t end_before[4];  // wave-uniform: paths known to end (sky, depth limit) in the tiles before tile t
     uint32_t n_ending = 0;
     uint32_t c_ev[6] = {0, 0, 0, 0, 0, 0};  // HL, HM, HD, SKY, DEPTHCUT, ABSORBED
     {
@@ -746,9 +746,8 @@ __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads, RRT_SH
             else c = h[t].y >> kLeafKindShift;
             classes |= c << (4u * t);
             if (c <= CL_DIEL) l_ent[lane + 64u * t] = rg[t];
-            const uint64_t em = __ballot(c == CL_SKY || c == CL_CUT);
-            end_rank[t] = n_ending + (uint32_t)__popcll(em & lt_mask);
-            n_ending += (uint32_t)__popcll(em);
+            end_before[t] = n_ending;
+            n_ending += (uint32_t)__popcll(__ballot(c == CL_SKY || c == CL_CUT));
             if (COUNT) {
 #pragma unroll
                 for (uint32_t k = 0; k < 5u; k++) c_ev[k] += (uint32_t)__popcll(__ballot(c == k));
@@ -800,7 +799,9 @@ __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads, RRT_SH
             const uint32_t pos = lane + 64u * t;
             const uint32_t cls = (classes >> (4u * t)) & 15u;
             bool alive = false, absorbed = false, started = false;
-            if (pos < count) shade_slot<MOVING, Tables>(S, T, P, Bt, C, cls, sq[t], cur, l_ent[pos], shard, claim0 + end_rank[t], alive, absorbed, started);
+            // claim number of the path that takes over an ending slot: ending slots take them in list order
+            const uint32_t end_rank = end_before[t] + (uint32_t)__popcll(__ballot(cls == CL_SKY || cls == CL_CUT) & lt_mask);
+            if (pos < count) shade_slot<MOVING, Tables>(S, T, P, Bt, C, cls, sq[t], cur, l_ent[pos], shard, claim0 + end_rank, alive, absorbed, started);
             absorbed_bits |= absorbed ? (1u << t) : 0u;
             alive_bits |= alive ? (1u << t) : 0u;
             n_started += (uint32_t)__popcll(__ballot(started));
