@@ -510,19 +510,26 @@ struct SlotIn {
     uint2 h;
     uint32_t depth;
     uint4 recent;  // the four most recent trail entries, newest first
+    float4 sph, mat;  // (tables in HBM only) the hit sphere's table rows, fetched with the rest of the state
 };
-DEV void load_slot(const PathState &P, bool active, uint32_t slot, SlotIn &in) {
+// `hit_word` is the sphere word of the slot's hit record as step 1 saw it, or kPrimNone: with it the table rows can be
+// asked for at once, a tile ahead, instead of by a dependent gather in the middle of the tile.
+template <bool PREFETCH_ROWS>
+DEV void load_slot(const SceneDev &S, const PathState &P, bool active, uint32_t slot, uint32_t hit_word, SlotIn &in) {
     if (active) { in.A = P.rayA[slot]; in.B = P.rayB[slot]; in.h = P.hit[slot]; in.depth = P.depth[slot]; in.recent = P.recent[slot]; }
+    if (PREFETCH_ROWS && active && hit_word != kPrimNone) { in.sph = S.sph[hit_word & kLeafPrimMask]; in.mat = S.prim_att[hit_word & kLeafPrimMask]; }
 }
 
 // Where shade reads the per-sphere tables from: HBM through the caches, or (small scenes) a copy in the block's LDS.  An
 // LDS read does not queue behind the kernel's outstanding stores the way a global load does.
 struct GlobalTables {
+    static constexpr bool kInLds = false;
     const float4 *sph, *att;
     DEV float4 sphere(uint32_t i) const { return sph[i]; }
     DEV float4 material(uint32_t i) const { return att[i]; }
 };
 struct LdsTables {
+    static constexpr bool kInLds = true;
     const float4 *sph, *att;  // both in LDS
     DEV float4 sphere(uint32_t i) const { return sph[i]; }
     DEV float4 material(uint32_t i) const { return att[i]; }
@@ -595,8 +602,8 @@ DEV void shade_slot(const SceneDev &S, const Tables &T, const PathState &P, cons
     } else if (cls != CL_NONE) {
         const uint32_t prim = in.h.y & kLeafPrimMask;
         const float t = u2f(in.h.x);
-        const float4 sp = T.sphere(prim);
-        const float mat_param = T.material(prim).w;  // fuzz or ref_idx
+        const float4 sp = Tables::kInLds ? T.sphere(prim) : in.sph;
+        const float mat_param = Tables::kInLds ? T.material(prim).w : in.mat.w;  // fuzz or ref_idx
         V3 c = mk(sp.x, sp.y, sp.z);
         if (MOVING) {
             if (S.sph_info[prim] & kInfoMovingBit) {  // sphere.rs:61-64
@@ -718,6 +725,7 @@ __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads, RRT_SH
 #endif
     // ---- 1. classify ----
     uint32_t sq[4];        // the slots at list positions lane + 64 t
+    uint32_t hw[4] = {kPrimNone, kPrimNone, kPrimNone, kPrimNone};  // (tables in HBM only) sphere word of their hit records
     uint32_t classes = 0;  // class of each of them, 4 bits apiece
     uint32_t end_before[4];  // wave-uniform: paths known to end (sky, depth limit) in the tiles before tile t
     uint32_t n_ending = 0;
@@ -745,6 +753,7 @@ __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads, RRT_SH
             else if ((dep[t] & 0xFFFFu) >= Bt.max_depth) c = CL_CUT;
             else c = h[t].y >> kLeafKindShift;
             classes |= c << (4u * t);
+            if (!TABLES && c <= CL_DIEL) hw[t] = h[t].y;
             if (c <= CL_DIEL) l_ent[lane + 64u * t] = rg[t];
             end_before[t] = n_ending;
             n_ending += (uint32_t)__popcll(__ballot(c == CL_SKY || c == CL_CUT));
@@ -759,7 +768,7 @@ __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads, RRT_SH
 
     // the first tile's state travels while the samples are drawn
     SlotIn cur, nxt;
-    load_slot(P, lane < count, sq[0], cur);
+    load_slot<!TABLES>(S, P, lane < count, sq[0], hw[0], cur);
 
 #ifdef RRT_SHADE_TIMING
     const uint64_t tk1 = __builtin_readcyclecounter();
@@ -795,7 +804,7 @@ __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads, RRT_SH
 #pragma unroll
     for (uint32_t t = 0; t < 4u; t++) {
         if (t < n_tiles) {
-            if (t + 1u < 4u) load_slot(P, lane + 64u * (t + 1u) < count, sq[(t + 1u) & 3u], nxt);
+            if (t + 1u < 4u) load_slot<!TABLES>(S, P, lane + 64u * (t + 1u) < count, sq[(t + 1u) & 3u], hw[(t + 1u) & 3u], nxt);
             const uint32_t pos = lane + 64u * t;
             const uint32_t cls = (classes >> (4u * t)) & 15u;
             bool alive = false, absorbed = false, started = false;
