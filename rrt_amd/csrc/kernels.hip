@@ -268,6 +268,20 @@ DEV uint32_t visit_inner(const Store &st, uint32_t cur, const RayCtx &r) {
     return (t0 <= t1) ? near_ref : exit_ref;  // the far child is the near child's exit link
 }
 
+// Correctly rounded square root of x >= 0 for the extend kernel's sphere test.  It is the sequence the compiler emits
+// for sqrtf (hardware estimate, then the neighbours one ulp down and up are tried against x with exact fma
+// residuals), without the rescaling of inputs below 2^-96 that the estimate cannot take: if any lane of the wave
+// has such an input the whole wave takes sqrtf.  Zero and +inf come out of the short sequence unchanged.
+DEV float sqrt_rn(float x) {
+    if (__builtin_expect(__ballot(x < 0x1p-96f) != 0ull, 0)) return sqrtf(x);
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float dn = u2f(f2u(s) - 1u), up = u2f(f2u(s) + 1u);
+    const float r_dn = __builtin_fmaf(-dn, s, x), r_up = __builtin_fmaf(-up, s, x);
+    float r = (r_dn <= 0.0f) ? dn : s;
+    r = (r_up > 0.0f) ? up : r;
+    return r;
+}
+
 // Sphere::hit (sphere.rs:68-85); the Hit record itself is rebuilt in shade, for the final hit only.  (Deferring the
 // square root and divisions until many lanes need them was tried: lanes that wait for roots cost the descent passes as
 // many idle lanes as the batched root passes save.)
@@ -282,7 +296,7 @@ DEV uint32_t visit_leaf(const Store &st, uint32_t cur, RayCtx &r) {
     const float cc = dot3(oc, oc) - rr;
     const float disc = (half_b * half_b) - (r.a * cc);
     if (!(disc < 0.0f)) {
-        const float sq = sqrtf(disc);
+        const float sq = sqrt_rn(disc);
         float root = (-half_b - sq) / r.a;
         bool outside = root < r.tmin || r.tmax < root;
         if (outside) {
