@@ -744,6 +744,7 @@ __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads, RRT_SH
     uint32_t end_before[4];  // wave-uniform: paths known to end (sky, depth limit) in the tiles before tile t
     uint32_t n_ending = 0;
     uint32_t c_ev[6] = {0, 0, 0, 0, 0, 0};  // HL, HM, HD, SKY, DEPTHCUT, ABSORBED
+    SlotIn cur, nxt;
     {
         uint2 h[4];
         uint32_t dep[4];
@@ -754,6 +755,8 @@ __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads, RRT_SH
 #pragma unroll
             for (uint32_t t = 0; t < 4u; t++) sq[t] = lane + 64u * t < count ? P.queue[base + lane + 64u * t] : 0u;
         }
+        // the first tile's ray and trail window travel together with everything the classification needs
+        if (lane < count) { cur.A = P.rayA[sq[0]]; cur.B = P.rayB[sq[0]]; cur.recent = P.recent[sq[0]]; }
 #pragma unroll
         for (uint32_t t = 0; t < 4u; t++) {
             h[t] = make_uint2(0u, 0u); dep[t] = 0u; rg[t] = make_uint4(0u, 0u, 0u, 0u);
@@ -776,13 +779,13 @@ __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads, RRT_SH
                 for (uint32_t k = 0; k < 5u; k++) c_ev[k] += (uint32_t)__popcll(__ballot(c == k));
             }
         }
+        cur.h = h[0]; cur.depth = dep[0];
+        if (!TABLES && hw[0] != kPrimNone) { cur.sph = S.sph[hw[0] & kLeafPrimMask]; cur.mat = S.prim_att[hw[0] & kLeafPrimMask]; }
     }
     const uint32_t n_tiles = (count + 63u) >> 6;
-    const uint32_t claim0 = claim_paths(Bt, lane, shard, n_ending);
-
-    // the first tile's state travels while the samples are drawn
-    SlotIn cur, nxt;
-    load_slot<!TABLES>(S, P, lane < count, sq[0], hw[0], cur);
+    // one cursor update for every path known to end; the answer is not needed before step 3
+    uint32_t claim_lane0 = 0;
+    if (lane == 0 && n_ending) claim_lane0 = atomicAdd(&Bt.cursors[shard * kCursorStride], n_ending);
 
 #ifdef RRT_SHADE_TIMING
     const uint64_t tk1 = __builtin_readcyclecounter();
@@ -815,6 +818,7 @@ __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads, RRT_SH
     // ---- 3. tiles ----
     uint32_t absorbed_bits = 0, alive_bits = 0;
     uint32_t n_started = 0;
+    const uint32_t claim0 = rfl(claim_lane0);
 #pragma unroll
     for (uint32_t t = 0; t < 4u; t++) {
         if (t < n_tiles) {
