@@ -48,7 +48,7 @@ constexpr uint32_t kDefaultSlots = 1u << 22;
 constexpr size_t kRadBudgetBytes = size_t(16) << 30;  // per-batch radiance planes; HBM is 288 GB
 constexpr uint32_t kMaxBatchPaths = 1u << 30;
 constexpr uint32_t kMaxParts = 4;       // parts of the path pool that run on streams of their own
-constexpr uint32_t kDefaultParts = 2;
+constexpr uint32_t kDefaultParts = 4;
 constexpr uint32_t kFlagWords = kMaxParts * 32 * 32;  // per part: 32 flag words, one per 128-byte line
 constexpr uint32_t kChunk = 8;  // extend+shade rounds queued between two looks at the alive flag
 constexpr uint32_t kMaxDepthLimit = 4096;  // depth and trail length share one 32-bit word per path

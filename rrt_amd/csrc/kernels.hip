@@ -319,17 +319,23 @@ DEV uint64_t wave_sum_u64(uint64_t v) {
 // lanes wait until at least `retire_min` of them can be retired and restarted in one go (or nothing else is left).
 template <class Store, bool MOVING, bool COUNT>
 DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uint32_t wave, uint32_t lane, uint32_t retire_min,
-                     uint32_t leaf_min, uint64_t *wave_stats) {
-    const uint32_t base = wave * kWaveSlots;
-    const uint32_t count = rfl(P.qcount[wave]);
+                     uint32_t leaf_min, uint64_t *wave_stats, uint32_t own_count, uint32_t *pool_head, uint32_t pool_base, uint32_t pool_total) {
+    // Where the wave's rays come from.  Usually (pool_head != null) from a pool shared by the waves of the workgroup:
+    // when every live-slot list of the workgroup is full, the lists are one run of consecutive slots, and idle lanes of
+    // any wave take the next ones off a counter in LDS.  All waves then stay busy until the run is used up, instead of
+    // each wave trailing off at the end of its own 256 rays.  Otherwise from the wave's own list.
+    const bool pooled = pool_head != nullptr;
+    const uint32_t base = pooled ? pool_base : wave * kWaveSlots;
+    const uint32_t count = pooled ? pool_total : own_count;
     if (count == 0) return;
+    uint32_t n_taken = 0;
     const bool uniform_times = st.uniform_times();
     uint32_t n_inner = 0, n_leaf = 0;
     uint32_t d_desc_iters = 0, d_desc_lanes = 0, d_leaf_iters = 0, d_leaf_lanes = 0, d_retires = 0, d_retire_lanes = 0;  // COUNT only
     // the lane's column of the live-slot list, read up front so that no ray load ever waits for a list load
     static_assert(kWaveSlots == 256, "four list entries per lane");
     uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-    if (count != kWaveSlots) {
+    if (!pooled && count != kWaveSlots) {
         q0 = lane < count ? P.queue[base + lane] : 0u;
         q1 = lane + 64u < count ? P.queue[base + lane + 64u] : 0u;
         q2 = lane + 128u < count ? P.queue[base + lane + 128u] : 0u;
@@ -349,9 +355,15 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
         if (~idle_m == 0ull || (uint32_t)__popcll(ready) >= retire_min) {
             if (COUNT) { d_retires++; d_retire_lanes += (uint32_t)__popcll(ready); }
             // every idle lane takes the next ray of the list, in lane order; list entry p sits in lane p % 64, register p / 64
+            const uint32_t n_idle = (uint32_t)__popcll(idle_m);
+            if (pooled && head < count) {  // `head` doubles as "the pool is not known to be empty"
+                uint32_t got = 0;
+                if (lane == 0) got = atomicAdd(pool_head, n_idle);
+                head = min(rfl(got), count);
+            }
             const uint32_t pos = head + (uint32_t)__popcll(idle_m & lt_mask);
             uint32_t n_slot = base + pos;  // a full list is every slot of the wave, in order
-            if (count != kWaveSlots) {
+            if (!pooled && count != kWaveSlots) {
                 const uint32_t col = pos >> 6;
                 const int src = (int)(pos & 63u);
                 const uint32_t s0 = (uint32_t)__shfl((int)q0, src, 64), s1 = (uint32_t)__shfl((int)q1, src, 64);
@@ -371,7 +383,8 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
                 cur = st.root();
                 has = true;
             }
-            head += min((uint32_t)__popcll(idle_m), count - head);
+            n_taken += (uint32_t)__popcll(__ballot(take));
+            head += min(n_idle, count - head);  // pooled: reaches `count` once a grab runs past the end of the pool
             if (__ballot(has) == 0ull) break;
         }
         // descend until no lane is at an inner node, or enough lanes wait at a sphere for a test to be worth a pass
@@ -403,16 +416,27 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
 #endif
         }
     }
-    if (lane == 0) stt[ST_RAYS] += count;
+    if (lane == 0) stt[ST_RAYS] += n_taken;
 }
 
 template <bool MOVING, bool COUNT>
 __global__ __launch_bounds__(kBlockThreads) void k_extend(SceneDev S, PathState P, uint32_t retire_min, uint32_t leaf_min, uint64_t *wave_stats) {
+    __shared__ uint32_t pool[2];  // next position of the workgroup's ray pool; sum of the workgroup's list lengths
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = P.wave_begin + ((blockIdx.x * kBlockThreads + threadIdx.x) >> 6);
+    const uint32_t wave0 = P.wave_begin + blockIdx.x * (kBlockThreads / 64u);
+    const uint32_t wave = wave0 + (threadIdx.x >> 6);
+    const uint32_t own_count = wave < P.wave_end ? rfl(P.qcount[wave]) : 0u;
+    if (threadIdx.x < 2) pool[threadIdx.x] = 0u;
+    __syncthreads();
+    if (lane == 0 && own_count) atomicAdd(&pool[1], own_count);
+    __syncthreads();
     if (wave >= P.wave_end) return;
+    const uint32_t n_lists = min(kBlockThreads / 64u, P.wave_end - wave0);
+    const uint32_t total = pool[1];
+    const bool pooled = total == n_lists * kWaveSlots;
     const HbmStore<MOVING> st(S);
-    extend_wave<HbmStore<MOVING>, MOVING, COUNT>(st, S, P, wave, lane, retire_min, leaf_min, wave_stats);
+    extend_wave<HbmStore<MOVING>, MOVING, COUNT>(st, S, P, wave, lane, retire_min, leaf_min, wave_stats, own_count, pooled ? &pool[0] : nullptr,
+                                                 wave0 * kWaveSlots, total);
 }
 
 constexpr uint32_t kLdsBlockThreads = 1024;  // 16 waves share one LDS copy of the scene
@@ -422,14 +446,24 @@ __global__ __launch_bounds__(kLdsBlockThreads, 8) void k_extend_lds(SceneDev S, 
                                                                   uint64_t *wave_stats) {
     extern __shared__ uint4 lds4[];
     const uint32_t n_vec = S.n_nodes * (kSmallWords / 2u);
+    __shared__ uint32_t pool[2];  // next position of the workgroup's ray pool; sum of the workgroup's list lengths
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave0 = P.wave_begin + blockIdx.x * (kLdsBlockThreads / 64u);
+    const uint32_t wave = wave0 + (threadIdx.x >> 6);
+    const uint32_t own_count = wave < P.wave_end ? rfl(P.qcount[wave]) : 0u;
+    if (threadIdx.x < 2) pool[threadIdx.x] = 0u;
     for (uint32_t i = threadIdx.x; i < n_vec; i += kLdsBlockThreads)
         reinterpret_cast<uint2 *>(lds4)[i] = reinterpret_cast<const uint2 *>(S.small_nodes)[i];
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = P.wave_begin + ((blockIdx.x * kLdsBlockThreads + threadIdx.x) >> 6);
+    if (lane == 0 && own_count) atomicAdd(&pool[1], own_count);
+    __syncthreads();
     if (wave >= P.wave_end) return;
+    const uint32_t n_lists = min(kLdsBlockThreads / 64u, P.wave_end - wave0);
+    const uint32_t total = pool[1];
+    const bool pooled = total == n_lists * kWaveSlots;
     const LdsStore<MOVING> st(lds4, S.small_root);
-    extend_wave<LdsStore<MOVING>, MOVING, COUNT>(st, S, P, wave, lane, retire_min, leaf_min, wave_stats);
+    extend_wave<LdsStore<MOVING>, MOVING, COUNT>(st, S, P, wave, lane, retire_min, leaf_min, wave_stats, own_count, pooled ? &pool[0] : nullptr,
+                                                 wave0 * kWaveSlots, total);
 }
 
 // (1 - cos)^5 of materials.rs:68, as a double-precision product rounded once to f32
