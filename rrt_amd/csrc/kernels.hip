@@ -583,11 +583,14 @@ struct LdsTables {
     DEV float4 material(uint32_t i) const { return att[i]; }
 };
 
+// A freshly generated path: camera ray and generator state (lib.rs:93-101)
+struct NewPath { float4 A, B; uint4 rng; bool ok; };
+
 // Step 3 for one lane.  `gw` is the slot's LDS entry: the generator state (before the accepted draw, for Lambertian and
-// metal).  `next_n` is the claim number of the path that takes over the slot if this one ends here.
+// metal).  `np` is the path that takes over the slot if this one ends here.
 template <bool MOVING, class Tables>
-DEV void shade_slot(const SceneDev &S, const Tables &T, const PathState &P, const BatchDev &Bt, const CameraDev &C, uint32_t cls, uint32_t slot,
-                    const SlotIn &in, uint4 gw, uint32_t shard, uint32_t next_n, bool &alive, bool &absorbed, bool &started) {
+DEV void shade_slot(const SceneDev &S, const Tables &T, const PathState &P, const BatchDev &Bt, uint32_t cls, uint32_t slot,
+                    const SlotIn &in, uint4 gw, const NewPath &np, bool &alive, bool &absorbed, bool &started) {
     const float4 A = in.A, B = in.B;
     const uint32_t depth = in.depth & 0xFFFFu;       // scatters so far
     const uint32_t trail_len = in.depth >> 16;       // of which recorded on the trail
@@ -714,14 +717,12 @@ DEV void shade_slot(const SceneDev &S, const Tables &T, const PathState &P, cons
     if (ended || absorbed) {
         Bt.rad[pid] = make_float4(rx, ry, rz, 0.0f);  // one 16-byte store per finished path
     }
-    if (ended) {
-        const uint64_t p64 = path_of_claim(Bt, shard, next_n);
-        if (p64 < (uint64_t)Bt.n_paths) {
-            generate_path(Bt, C, (uint32_t)p64, oA, oB, g);
-            o_depth = 0u;
-            alive = true;
-            started = true;
-        }
+    if (ended && np.ok) {  // the slot's next path, generated beforehand (see k_shade)
+        oA = np.A; oB = np.B;
+        g.s0 = np.rng.x; g.s1 = np.rng.y; g.s2 = np.rng.z; g.s3 = np.rng.w;
+        o_depth = 0u;
+        alive = true;
+        started = true;
     }
     if (alive) {
         P.rayA[slot] = oA;
@@ -731,6 +732,17 @@ DEV void shade_slot(const SceneDev &S, const Tables &T, const PathState &P, cons
         P.depth[slot] = o_depth;
         P.recent[slot] = o_recent;  // also where nothing changed: a store that covers whole lines costs the memory system less than a sparse one
     }
+}
+
+// Lane `src`'s new path, for every lane (12 ds_bpermute)
+DEV NewPath fetch_path(const NewPath &g, int src) {
+    NewPath r;
+    r.A = make_float4(__shfl(g.A.x, src, 64), __shfl(g.A.y, src, 64), __shfl(g.A.z, src, 64), __shfl(g.A.w, src, 64));
+    r.B = make_float4(__shfl(g.B.x, src, 64), __shfl(g.B.y, src, 64), __shfl(g.B.z, src, 64), __shfl(g.B.w, src, 64));
+    r.rng = make_uint4((uint32_t)__shfl((int)g.rng.x, src, 64), (uint32_t)__shfl((int)g.rng.y, src, 64), (uint32_t)__shfl((int)g.rng.z, src, 64),
+                       (uint32_t)__shfl((int)g.rng.w, src, 64));
+    r.ok = __shfl(g.ok ? 1 : 0, src, 64) != 0;
+    return r;
 }
 
 template <bool MOVING, bool COUNT, bool TABLES>
@@ -853,6 +865,12 @@ __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads, RRT_SH
     uint32_t absorbed_bits = 0, alive_bits = 0;
     uint32_t n_started = 0;
     const uint32_t claim0 = rfl(claim_lane0);
+    // New paths for the slots whose path ends are generated 64 at a time with every lane busy (lane i makes the path of
+    // the wave's ending slot gen_first + i) and stay in registers; the lane that owns an ending slot fetches its path
+    // from there (ds_bpermute) when its tile comes up.
+    NewPath gen;
+    gen.A = gen.B = make_float4(0.0f, 0.0f, 0.0f, 0.0f); gen.rng = make_uint4(0u, 0u, 0u, 0u); gen.ok = false;
+    uint32_t gen_first = 0, gen_end = 0;  // ending slots [gen_first, gen_end) are in `gen`
 #pragma unroll
     for (uint32_t t = 0; t < 4u; t++) {
         if (t < n_tiles) {
@@ -860,9 +878,32 @@ __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads, RRT_SH
             const uint32_t pos = lane + 64u * t;
             const uint32_t cls = (classes >> (4u * t)) & 15u;
             bool alive = false, absorbed = false, started = false;
-            // claim number of the path that takes over an ending slot: ending slots take them in list order
-            const uint32_t end_rank = end_before[t] + (uint32_t)__popcll(__ballot(cls == CL_SKY || cls == CL_CUT) & lt_mask);
-            if (pos < count) shade_slot<MOVING, Tables>(S, T, P, Bt, C, cls, sq[t], cur, l_ent[pos], shard, claim0 + end_rank, alive, absorbed, started);
+            // ending slots take the claimed path ids in list order
+            const bool ending = cls == CL_SKY || cls == CL_CUT;
+            const uint64_t end_m = __ballot(ending);
+            const uint32_t end_rank = end_before[t] + (uint32_t)__popcll(end_m & lt_mask);
+            const uint32_t end_hi = end_before[t] + (uint32_t)__popcll(end_m);
+            NewPath np;
+            np.A = np.B = make_float4(0.0f, 0.0f, 0.0f, 0.0f); np.rng = make_uint4(0u, 0u, 0u, 0u); np.ok = false;
+            for (uint32_t have = end_before[t]; have < end_hi;) {
+                if (gen_end <= have) {  // generate the next 64
+                    gen_first = gen_end;
+                    gen_end = gen_first + 64u;
+                    const uint64_t p64 = path_of_claim(Bt, shard, claim0 + gen_first + lane);
+                    gen.ok = gen_first + lane < n_ending && p64 < (uint64_t)Bt.n_paths;
+                    if (gen.ok) {
+                        Rng g;
+                        generate_path(Bt, C, (uint32_t)p64, gen.A, gen.B, g);
+                        gen.rng = make_uint4(g.s0, g.s1, g.s2, g.s3);
+                    }
+                }
+                const int src = (int)((end_rank - gen_first) & 63u);
+                const bool mine = ending && end_rank >= have && end_rank < gen_end;
+                const NewPath got = fetch_path(gen, src);
+                if (mine) np = got;
+                have = min(gen_end, end_hi);
+            }
+            if (pos < count) shade_slot<MOVING, Tables>(S, T, P, Bt, cls, sq[t], cur, l_ent[pos], np, alive, absorbed, started);
             absorbed_bits |= absorbed ? (1u << t) : 0u;
             alive_bits |= alive ? (1u << t) : 0u;
             n_started += (uint32_t)__popcll(__ballot(started));
