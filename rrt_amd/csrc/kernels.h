@@ -30,7 +30,7 @@ struct SceneDev {
     const uint32_t *sph_info;
     const float4 *mat;        // {albedo, fuzz | ref_idx} per material
     const float4 *pmat;       // the same, per sphere: one gather less in shade
-    const float4 *prim_att;   // per sphere: attenuation rgb, fuzz or ref_idx
+    const float4 *prim_att;   // per sphere: attenuation rgb, fuzz; glass: 1/ior, r0 front, r0 back, ior
     uint32_t flags;
     float u_time0, u_dt;
     // compact copy for LDS residency (null when the scene does not qualify; see scene_layout.h)

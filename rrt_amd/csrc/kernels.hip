@@ -33,8 +33,22 @@ DEV V3 scale(float s, V3 a) { return mk(s * a.x, s * a.y, s * a.z); }
 DEV V3 neg(V3 a) { return mk(-a.x, -a.y, -a.z); }
 // ultraviolet Vec4::dot with both w lanes zero: x.mul_add(ox, y.mul_add(oy, z.mul_add(oz, 0)))
 DEV float dot3(V3 a, V3 b) { return __builtin_fmaf(a.x, b.x, __builtin_fmaf(a.y, b.y, __builtin_fmaf(a.z, b.z, 0.0f))); }
+// Correctly rounded square root.  It is the sequence the compiler emits
+// for sqrtf (hardware estimate, then the neighbours one ulp down and up are tried against x with exact fma
+// residuals), without the rescaling of inputs below 2^-96 that the estimate cannot take: if any lane of the wave
+// has such an input the whole wave takes sqrtf.  Zero and +inf come out of the short sequence unchanged.
+DEV float sqrt_rn(float x) {
+    if (__builtin_expect(__ballot(x < 0x1p-96f) != 0ull, 0)) return sqrtf(x);
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float dn = u2f(f2u(s) - 1u), up = u2f(f2u(s) + 1u);
+    const float r_dn = __builtin_fmaf(-dn, s, x), r_up = __builtin_fmaf(-up, s, x);
+    float r = (r_dn <= 0.0f) ? dn : s;
+    r = (r_up > 0.0f) ? up : r;
+    return r;
+}
+
 // ultraviolet normalized(): reciprocal of the magnitude, then one multiply per lane
-DEV V3 normalized(V3 a) { const float r = 1.0f / sqrtf(dot3(a, a)); return mk(a.x * r, a.y * r, a.z * r); }
+DEV V3 normalized(V3 a) { const float r = 1.0f / sqrt_rn(dot3(a, a)); return mk(a.x * r, a.y * r, a.z * r); }
 // the multiply half of normalized(): a * (1 / |a|), each component times the reciprocal
 DEV V3 scale_r(V3 a, float r) { return mk(a.x * r, a.y * r, a.z * r); }
 // ultraviolet reflected(): self - (2 * self.dot(n)) * n
@@ -268,20 +282,6 @@ DEV uint32_t visit_inner(const Store &st, uint32_t cur, const RayCtx &r) {
     return (t0 <= t1) ? near_ref : exit_ref;  // the far child is the near child's exit link
 }
 
-// Correctly rounded square root of x >= 0 for the extend kernel's sphere test.  It is the sequence the compiler emits
-// for sqrtf (hardware estimate, then the neighbours one ulp down and up are tried against x with exact fma
-// residuals), without the rescaling of inputs below 2^-96 that the estimate cannot take: if any lane of the wave
-// has such an input the whole wave takes sqrtf.  Zero and +inf come out of the short sequence unchanged.
-DEV float sqrt_rn(float x) {
-    if (__builtin_expect(__ballot(x < 0x1p-96f) != 0ull, 0)) return sqrtf(x);
-    const float s = __builtin_amdgcn_sqrtf(x);
-    const float dn = u2f(f2u(s) - 1u), up = u2f(f2u(s) + 1u);
-    const float r_dn = __builtin_fmaf(-dn, s, x), r_up = __builtin_fmaf(-up, s, x);
-    float r = (r_dn <= 0.0f) ? dn : s;
-    r = (r_up > 0.0f) ? up : r;
-    return r;
-}
-
 // Sphere::hit (sphere.rs:68-85); the Hit record itself is rebuilt in shade, for the final hit only.  (Deferring the
 // square root and divisions until many lanes need them was tried: lanes that wait for roots cost the descent passes as
 // many idle lanes as the batched root passes save.)
@@ -468,11 +468,8 @@ __global__ __launch_bounds__(kLdsBlockThreads, 8) void k_extend_lds(SceneDev S, 
 
 // (1 - cos)^5 of materials.rs:68, as a double-precision product rounded once to f32
 DEV float pow5(float x) { const double d = (double)x, d2 = d * d, d4 = d2 * d2; return (float)(d4 * d); }
-DEV float reflectance(float cosine, float ref_idx) {  // materials.rs:65-69
-    const float q = (1.0f - ref_idx) / (1.0f + ref_idx);
-    const float r0 = q * q;
-    return r0 + (1.0f - r0) * pow5(1.0f - cosine);
-}
+// materials.rs:65-69 with r0 = ((1 - ratio) / (1 + ratio))^2 taken from the sphere's table row (same f32 operations, done once on the host)
+DEV float reflectance(float cosine, float r0) { return r0 + (1.0f - r0) * pow5(1.0f - cosine); }
 
 // Path ids are dealt in groups of 64 consecutive ids, group g belonging to cursor shard g % n_shards; a wave draws
 // from shard wave % n_shards.  `n` is the wave's running count of claims from its shard.
@@ -607,7 +604,7 @@ DEV void shade_slot(const SceneDev &S, const Tables &T, const PathState &P, cons
     bool ended = false;
     // 1 / |d|, shared by everything that needs the unit direction: the sky (lib.rs:67), metal (materials.rs:47) and glass (materials.rs:83)
     float inv_len = 0.0f;
-    if (cls == CL_METAL || cls == CL_DIEL || cls == CL_SKY) inv_len = 1.0f / sqrtf(dot3(d, d));
+    if (cls == CL_METAL || cls == CL_DIEL || cls == CL_SKY) inv_len = 1.0f / sqrt_rn(dot3(d, d));
     if (cls == CL_SKY) {
         // sky (lib.rs:66-70), then the product of attenuations innermost first (lib.rs:62).  The spheres scattered off
         // on the way are read back from the trail, eight levels per round so that a long path costs few memory round
@@ -654,7 +651,8 @@ DEV void shade_slot(const SceneDev &S, const Tables &T, const PathState &P, cons
         const uint32_t prim = in.h.y & kLeafPrimMask;
         const float t = u2f(in.h.x);
         const float4 sp = Tables::kInLds ? T.sphere(prim) : in.sph;
-        const float mat_param = Tables::kInLds ? T.material(prim).w : in.mat.w;  // fuzz or ref_idx
+        const float4 mrow = Tables::kInLds ? T.material(prim) : in.mat;  // metal: .w = fuzz; glass: 1/ior, r0 seen from outside, r0 from inside, ior
+        const float mat_param = mrow.w;
         V3 c = mk(sp.x, sp.y, sp.z);
         if (MOVING) {
             if (S.sph_info[prim] & kInfoMovingBit) {  // sphere.rs:61-64
@@ -683,20 +681,20 @@ DEV void shade_slot(const SceneDev &S, const Tables &T, const PathState &P, cons
             dir = add(refl, scale(fuzz, smp));
             scattered = dot3(dir, n) > 0.0f;
         } else {  // materials.rs:75-104
-            const float ref_idx = mat_param;
-            const float ratio = front ? 1.0f / ref_idx : ref_idx;
+            const float ratio = front ? mrow.x : mrow.w;  // 1.0 / ref_idx : ref_idx (materials.rs:80)
+            const float r0 = front ? mrow.y : mrow.z;
             const V3 ud = scale_r(d, inv_len);
             const float cos_theta = fminf(dot3(neg(ud), n), 1.0f);
-            const float sin_theta = sqrtf(1.0f - (cos_theta * cos_theta));
+            const float sin_theta = sqrt_rn(1.0f - (cos_theta * cos_theta));
             bool reflect = ratio * sin_theta > 1.0f;
-            if (!reflect) reflect = reflectance(cos_theta, ratio) > gen_f32(g);  // the draw happens only here (materials.rs:89)
+            if (!reflect) reflect = reflectance(cos_theta, r0) > gen_f32(g);  // the draw happens only here (materials.rs:89)
             if (reflect) {
                 dir = reflected(ud, n);
             } else {  // ultraviolet refracted()
                 const float ndi = dot3(n, ud);
                 const float k = 1.0f - ratio * ratio * (1.0f - ndi * ndi);
                 if (k < 0.0f) dir = mk(0.0f, 0.0f, 0.0f);
-                else dir = sub(scale(ratio, ud), scale(ratio * ndi + sqrtf(k), n));
+                else dir = sub(scale(ratio, ud), scale(ratio * ndi + sqrt_rn(k), n));
             }
         }
         if (scattered) {

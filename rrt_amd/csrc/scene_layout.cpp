@@ -60,7 +60,13 @@ int build_scene_layout(const rrt_sphere_soa *sp, const rrt_material_soa *mt, con
         out.motion_dt[i] = sp->time1[i] - sp->time0[i];
         out.sph_info[i] = m | (mt->kind[m] << kInfoKindShift) | (still ? 0u : kInfoMovingBit);
         out.pmat[i] = out.mat[m];
-        if (mt->kind[m] == RRT_MAT_DIELECTRIC) out.prim_att[i] = Float4{1.f, 1.f, 1.f, out.mat[m].w};
+        if (mt->kind[m] == RRT_MAT_DIELECTRIC) {
+            // a glass sphere is never on a path's trail (its attenuation is 1), so the colour lanes of its row carry what
+            // Dielectric::scatter derives from ref_idx alone (materials.rs:80, 66-67), in the same f32 operations
+            const float ior = out.mat[m].w, inv = 1.0f / ior;
+            const float qf = (1.0f - inv) / (1.0f + inv), qb = (1.0f - ior) / (1.0f + ior);
+            out.prim_att[i] = Float4{inv, qf * qf, qb * qb, ior};
+        }
         else out.prim_att[i] = Float4{mt->albedo_r[m], mt->albedo_g[m], mt->albedo_b[m], out.mat[m].w};
         if (!still) {
             if (!any_moving) { ut0 = f2u(sp->time0[i]); ut1 = f2u(sp->time1[i]); out.u_time0 = sp->time0[i]; out.u_dt = out.motion_dt[i]; }

@@ -66,7 +66,7 @@ struct SceneLayout {
     std::vector<uint32_t> sph_info; // see kInfo*
     std::vector<Float4> mat;        // {albedo rgb, fuzz or ref_idx}
     std::vector<Float4> pmat;       // mat[material of sphere i]
-    std::vector<Float4> prim_att;   // attenuation of a scatter off this sphere (materials.rs:32,55,101), and its fuzz or ref_idx
+    std::vector<Float4> prim_att;   // attenuation of a scatter off this sphere (materials.rs:32,55) and its fuzz; glass: {1/ior, r0 front, r0 back, ior}
     uint32_t n_spheres = 0;
     uint32_t flags = 0;
     float u_time0 = 0.f, u_dt = 1.f;
