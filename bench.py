@@ -184,9 +184,9 @@ def main():
                 "unit": "TFLOP/s", "frac": round(flops / sec / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 4), "traffic": traffic,
                 "launches": ext_launches, "avg_launch_ms": round(ext_ms / max(1, ext_launches), 4),
                 "flop_per_launch": round(flops / max(1, ext_launches)),
-                "note": "extend launches of the two halves of the path pool run on two streams and overlap each other and the shade "
-                        "kernel, so the summed launch durations exceed wall time and `achieved` is a lower bound; `isolated` is the "
-                        "same kernel on the whole pool with nothing beside it (one extra step on one stream)",
+                "note": "extend launches of the parts of the path pool run on streams of their own and overlap each other and the "
+                        "shade kernel, so the summed launch durations exceed wall time and `achieved` is a lower bound; `isolated` is "
+                        "the same kernel on the whole pool with nothing beside it (one extra step on one stream)",
                 "isolated": {"achieved": round(extend_flops(cst) / (ist["extend_ms"] * 1e-3) / 1e12, 3),
                              "frac": round(extend_flops(cst) / (ist["extend_ms"] * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 4),
                              "launches": ist["extend_launches"], "avg_launch_ms": round(ist["extend_ms"] / max(1, ist["extend_launches"]), 4),
