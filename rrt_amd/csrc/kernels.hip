@@ -788,7 +788,7 @@ __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads, RRT_SH
     uint32_t end_before[4];  // wave-uniform: paths known to end (sky, depth limit) in the tiles before tile t
     uint32_t n_ending = 0;
     uint32_t c_ev[6] = {0, 0, 0, 0, 0, 0};  // HL, HM, HD, SKY, DEPTHCUT, ABSORBED
-    SlotIn cur, nxt;
+    SlotIn buf[2];  // tile t reads buf[t & 1] while tile t + 1 loads into the other
     {
         uint2 h[4];
         uint32_t dep[4];
@@ -800,7 +800,7 @@ __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads, RRT_SH
             for (uint32_t t = 0; t < 4u; t++) sq[t] = lane + 64u * t < count ? P.queue[base + lane + 64u * t] : 0u;
         }
         // the first tile's ray and trail window travel together with everything the classification needs
-        if (lane < count) { cur.A = P.rayA[sq[0]]; cur.B = P.rayB[sq[0]]; cur.recent = P.recent[sq[0]]; }
+        if (lane < count) { buf[0].A = P.rayA[sq[0]]; buf[0].B = P.rayB[sq[0]]; buf[0].recent = P.recent[sq[0]]; }
 #pragma unroll
         for (uint32_t t = 0; t < 4u; t++) {
             h[t] = make_uint2(0u, 0u); dep[t] = 0u; rg[t] = make_uint4(0u, 0u, 0u, 0u);
@@ -823,8 +823,8 @@ __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads, RRT_SH
                 for (uint32_t k = 0; k < 5u; k++) c_ev[k] += (uint32_t)__popcll(__ballot(c == k));
             }
         }
-        cur.h = h[0]; cur.depth = dep[0];
-        if (!TABLES && hw[0] != kPrimNone) { cur.sph = S.sph[hw[0] & kLeafPrimMask]; cur.mat = S.prim_att[hw[0] & kLeafPrimMask]; }
+        buf[0].h = h[0]; buf[0].depth = dep[0];
+        if (!TABLES && hw[0] != kPrimNone) { buf[0].sph = S.sph[hw[0] & kLeafPrimMask]; buf[0].mat = S.prim_att[hw[0] & kLeafPrimMask]; }
     }
     const uint32_t n_tiles = (count + 63u) >> 6;
     // one cursor update for every path known to end; the answer is not needed before step 3
@@ -872,7 +872,7 @@ __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads, RRT_SH
 #pragma unroll
     for (uint32_t t = 0; t < 4u; t++) {
         if (t < n_tiles) {
-            if (t + 1u < 4u) load_slot<!TABLES>(S, P, lane + 64u * (t + 1u) < count, sq[(t + 1u) & 3u], hw[(t + 1u) & 3u], nxt);
+            if (t + 1u < 4u) load_slot<!TABLES>(S, P, lane + 64u * (t + 1u) < count, sq[(t + 1u) & 3u], hw[(t + 1u) & 3u], buf[(t + 1u) & 1u]);
             const uint32_t pos = lane + 64u * t;
             const uint32_t cls = (classes >> (4u * t)) & 15u;
             bool alive = false, absorbed = false, started = false;
@@ -901,11 +901,10 @@ __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads, RRT_SH
                 if (mine) np = got;
                 have = min(gen_end, end_hi);
             }
-            if (pos < count) shade_slot<MOVING, Tables>(S, T, P, Bt, cls, sq[t], cur, l_ent[pos], np, alive, absorbed, started);
+            if (pos < count) shade_slot<MOVING, Tables>(S, T, P, Bt, cls, sq[t], buf[t & 1u], l_ent[pos], np, alive, absorbed, started);
             absorbed_bits |= absorbed ? (1u << t) : 0u;
             alive_bits |= alive ? (1u << t) : 0u;
             n_started += (uint32_t)__popcll(__ballot(started));
-            cur = nxt;
         }
     }
 
