@@ -61,7 +61,7 @@ struct rrt_ctx {
     hipEvent_t ev_fork = nullptr, ev_join[kMaxParts - 1] = {};
     hipDeviceProp_t prop{};
     // scene
-    DevBuf nodes, small_nodes, sph, motion, motion_dt, sph_info, mat, pmat, prim_att;
+    DevBuf nodes, small_nodes, sph, motion, motion_dt, sph_info, prim_att;
     SceneDev sd{};
     bool has_scene = false, moving = false;
     uint32_t n_spheres = 0, n_nodes = 0;
@@ -120,7 +120,7 @@ void rrt_destroy(rrt_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (hipStream_t ss : c->side_stream) if (ss) (void)hipStreamSynchronize(ss);
-    for (DevBuf *b : {&c->nodes, &c->small_nodes, &c->sph, &c->motion, &c->motion_dt, &c->sph_info, &c->mat, &c->pmat, &c->prim_att, &c->rayA, &c->rayB, &c->rayC, &c->recent, &c->rng,
+    for (DevBuf *b : {&c->nodes, &c->small_nodes, &c->sph, &c->motion, &c->motion_dt, &c->sph_info, &c->prim_att, &c->rayA, &c->rayB, &c->rayC, &c->recent, &c->rng,
                       &c->depth, &c->hit, &c->trail, &c->queue, &c->qcount, &c->wave_stats, &c->cursors, &c->flags, &c->stats_out,
                       &c->accum, &c->rad, &c->pixel_map, &c->tmp_rgb, &c->tmp_acc, &c->q_org, &c->q_dir, &c->q_time, &c->q_t, &c->q_obj})
         b->release();
@@ -163,9 +163,7 @@ int rrt_upload_scene(rrt_ctx *c, const rrt_sphere_soa *sp, const rrt_material_so
     HIP_TRY(up(c->motion, L.motion.data(), L.motion.size() * sizeof(Float4)));
     HIP_TRY(up(c->motion_dt, L.motion_dt.data(), L.motion_dt.size() * 4));
     HIP_TRY(up(c->sph_info, L.sph_info.data(), L.sph_info.size() * 4));
-    HIP_TRY(up(c->mat, L.mat.data(), L.mat.size() * sizeof(Float4)));
     HIP_TRY(up(c->prim_att, L.prim_att.data(), L.prim_att.size() * sizeof(Float4)));
-    HIP_TRY(up(c->pmat, L.pmat.data(), L.pmat.size() * sizeof(Float4)));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->sd.nodes = c->nodes.as<uint4>();
     c->sd.root_ref = L.root_ref;
@@ -173,8 +171,6 @@ int rrt_upload_scene(rrt_ctx *c, const rrt_sphere_soa *sp, const rrt_material_so
     c->sd.motion = c->motion.as<float4>();
     c->sd.motion_dt = c->motion_dt.as<float>();
     c->sd.sph_info = c->sph_info.as<uint32_t>();
-    c->sd.mat = c->mat.as<float4>();
-    c->sd.pmat = c->pmat.as<float4>();
     c->sd.prim_att = c->prim_att.as<float4>();
     c->sd.flags = L.flags;
     c->sd.u_time0 = L.u_time0;

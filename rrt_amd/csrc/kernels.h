@@ -28,8 +28,6 @@ struct SceneDev {
     const float4 *motion;     // {centre1 - centre0, time0}
     const float *motion_dt;   // time1 - time0
     const uint32_t *sph_info;
-    const float4 *mat;        // {albedo, fuzz | ref_idx} per material
-    const float4 *pmat;       // the same, per sphere: one gather less in shade
     const float4 *prim_att;   // per sphere: attenuation rgb, fuzz; glass: 1/ior, r0 front, r0 back, ior
     uint32_t flags;
     float u_time0, u_dt;

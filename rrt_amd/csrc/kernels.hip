@@ -744,10 +744,7 @@ DEV NewPath fetch_path(const NewPath &g, int src) {
 }
 
 template <bool MOVING, bool COUNT, bool TABLES>
-#ifndef RRT_SHADE_WAVES
-#define RRT_SHADE_WAVES 1
-#endif
-__global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads, RRT_SHADE_WAVES) void k_shade(SceneDev S, PathState P, BatchDev Bt, CameraDev C,
+__global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads) void k_shade(SceneDev S, PathState P, BatchDev Bt, CameraDev C,
                                                                                       uint64_t *wave_stats) {
     constexpr uint32_t kThreads = TABLES ? kShadeTableThreads : kBlockThreads;
     extern __shared__ uint4 lds4[];  // per wave kShadeLdsWords words, then (TABLES) the sphere and material tables

@@ -42,7 +42,7 @@ int build_scene_layout(const rrt_sphere_soa *sp, const rrt_material_soa *mt, con
     }
 
     // ---- spheres ----
-    out.sph.resize(ns); out.motion.resize(ns); out.motion_dt.resize(ns); out.sph_info.resize(ns); out.prim_att.resize(ns); out.pmat.resize(ns);
+    out.sph.resize(ns); out.motion.resize(ns); out.motion_dt.resize(ns); out.sph_info.resize(ns); out.prim_att.resize(ns);
     bool any_moving = false, uniform = true;
     uint32_t ut0 = 0, ut1 = 0;
     for (uint32_t i = 0; i < ns; i++) {
@@ -59,7 +59,6 @@ int build_scene_layout(const rrt_sphere_soa *sp, const rrt_material_soa *mt, con
         out.motion[i] = Float4{c1[0] - c0[0], c1[1] - c0[1], c1[2] - c0[2], sp->time0[i]};
         out.motion_dt[i] = sp->time1[i] - sp->time0[i];
         out.sph_info[i] = m | (mt->kind[m] << kInfoKindShift) | (still ? 0u : kInfoMovingBit);
-        out.pmat[i] = out.mat[m];
         if (mt->kind[m] == RRT_MAT_DIELECTRIC) {
             // a glass sphere is never on a path's trail (its attenuation is 1), so the colour lanes of its row carry what
             // Dielectric::scatter derives from ref_idx alone (materials.rs:80, 66-67), in the same f32 operations

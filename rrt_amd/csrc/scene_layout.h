@@ -65,7 +65,6 @@ struct SceneLayout {
     std::vector<float> motion_dt;   // time1 - time0
     std::vector<uint32_t> sph_info; // see kInfo*
     std::vector<Float4> mat;        // {albedo rgb, fuzz or ref_idx}
-    std::vector<Float4> pmat;       // mat[material of sphere i]
     std::vector<Float4> prim_att;   // attenuation of a scatter off this sphere (materials.rs:32,55) and its fuzz; glass: {1/ior, r0 front, r0 back, ior}
     uint32_t n_spheres = 0;
     uint32_t flags = 0;
