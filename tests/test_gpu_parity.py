@@ -143,6 +143,19 @@ def test_schedule_independence(gpu_ctx):
         assert_same_image(gpu, ref)
 
 
+def test_pool_parts_and_streams_do_not_change_the_image(gpu_ctx, monkeypatch):
+    """The path pool worked as 1..4 parts on as many streams (RRT_STREAMS), with a pool big enough for the workgroup-wide
+    ray hand-out of the extend kernel to be in use: same bits every time."""
+    nx, ny, ns = 320, 200, 24
+    osc = OracleScene.build(SCENES["chap12"], nx, ny, seed=0)
+    upload_from_oracle(gpu_ctx, osc)
+    ref = osc.render(nx, ny, ns, seed=4, threads=8)
+    for parts in ["1", "2", "3", "4"]:
+        monkeypatch.setenv("RRT_STREAMS", parts)
+        gpu = gpu_ctx.render(rrt_amd.Context.params(nx, ny, ns, seed=4, path_slots=256 * 1024))
+        assert_same_image(gpu, ref)
+
+
 def test_tile_sharding_composes_to_the_unsharded_image(gpu_ctx):
     nx, ny, ns = 100, 37, 6   # not a multiple of the 32x8 tile in either direction
     osc = OracleScene.build(SCENES["chap12"], nx, ny, seed=0)
