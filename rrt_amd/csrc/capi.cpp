@@ -61,7 +61,7 @@ struct rrt_ctx {
     hipEvent_t ev_fork = nullptr, ev_join[kMaxParts - 1] = {};
     hipDeviceProp_t prop{};
     // scene
-    DevBuf nodes, small_nodes, sph, motion, motion_dt, sph_info, prim_att;
+    DevBuf nodes, small_nodes, top_nodes, sph, motion, motion_dt, sph_info, prim_att;
     SceneDev sd{};
     bool has_scene = false, moving = false;
     uint32_t n_spheres = 0, n_nodes = 0;
@@ -120,7 +120,7 @@ void rrt_destroy(rrt_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (hipStream_t ss : c->side_stream) if (ss) (void)hipStreamSynchronize(ss);
-    for (DevBuf *b : {&c->nodes, &c->small_nodes, &c->sph, &c->motion, &c->motion_dt, &c->sph_info, &c->prim_att, &c->rayA, &c->rayB, &c->rayC, &c->recent, &c->rng,
+    for (DevBuf *b : {&c->nodes, &c->small_nodes, &c->top_nodes, &c->sph, &c->motion, &c->motion_dt, &c->sph_info, &c->prim_att, &c->rayA, &c->rayB, &c->rayC, &c->recent, &c->rng,
                       &c->depth, &c->hit, &c->trail, &c->queue, &c->qcount, &c->wave_stats, &c->cursors, &c->flags, &c->stats_out,
                       &c->accum, &c->rad, &c->pixel_map, &c->tmp_rgb, &c->tmp_acc, &c->q_org, &c->q_dir, &c->q_time, &c->q_t, &c->q_obj})
         b->release();
@@ -150,6 +150,7 @@ int rrt_upload_scene(rrt_ctx *c, const rrt_sphere_soa *sp, const rrt_material_so
     std::string err;
     int rc = build_scene_layout(sp, mt, nodes, n_nodes, L, err);
     if (rc != RRT_OK) return fail(rc, err);
+    make_top_tree(L);
     HIP_TRY(hipSetDevice(c->device));
     c->has_scene = false;
     auto up = [&](DevBuf &b, const void *src, size_t bytes) -> hipError_t {
@@ -159,6 +160,7 @@ int rrt_upload_scene(rrt_ctx *c, const rrt_sphere_soa *sp, const rrt_material_so
     };
     HIP_TRY(up(c->nodes, L.nodes.data(), L.nodes.size() * 4));
     HIP_TRY(up(c->small_nodes, L.small_nodes.data(), L.small_nodes.size() * 4));
+    HIP_TRY(up(c->top_nodes, L.top_nodes.data(), L.top_nodes.size() * 4));
     HIP_TRY(up(c->sph, L.sph.data(), L.sph.size() * sizeof(Float4)));
     HIP_TRY(up(c->motion, L.motion.data(), L.motion.size() * sizeof(Float4)));
     HIP_TRY(up(c->motion_dt, L.motion_dt.data(), L.motion_dt.size() * 4));
@@ -180,6 +182,8 @@ int rrt_upload_scene(rrt_ctx *c, const rrt_sphere_soa *sp, const rrt_material_so
     c->sd.small_root = L.small_root;
     c->sd.n_nodes = L.n_nodes;
     c->sd.n_spheres = L.n_spheres;
+    c->sd.top_nodes = L.top_nodes.empty() ? nullptr : c->top_nodes.as<uint4>();
+    c->sd.n_top = (uint32_t)(L.top_nodes.size() / kNodeWords);
     c->moving = (L.flags & kSceneHasMoving) != 0;
     c->n_spheres = L.n_spheres;
     c->n_nodes = L.n_nodes;

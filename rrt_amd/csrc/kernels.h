@@ -37,6 +37,9 @@ struct SceneDev {
     uint32_t small_root;    // reference of the root
     uint32_t n_nodes;
     uint32_t n_spheres;
+    // copy of the top levels of the tree for scenes without a compact copy (references with kRefTopBit index it), or null
+    const uint4 *top_nodes;
+    uint32_t n_top;
 };
 
 // All per-path state lives in planes indexed by slot.  A wave owns slots [wave*kWaveSlots, +kWaveSlots)

@@ -172,32 +172,49 @@ DEV void ray_setup(RayCtx &r, float4 A, float4 B, float tmin, float tmax, const 
     ray_finish(r, tmin, tmax, S, uniform_times);
 }
 
-template <bool MOVING>
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef const u32x4 *HbmNodePtr;
+typedef const __attribute__((address_space(3))) u32x4 *LdsNodePtr;  // spelled out so that the loads are ds_read, not flat_load
+template <class Ptr>
+DEV uint4 load4(Ptr p, uint32_t i) { const u32x4 v = p[i]; return make_uint4(v.x, v.y, v.z, v.w); }
+
+template <bool MOVING, class TopPtr = HbmNodePtr>
 struct HbmStore {
     static constexpr uint32_t kEnd = kRefEnd;
     const SceneDev &S;
-    DEV explicit HbmStore(const SceneDev &s) : S(s) {}
+    TopPtr top;  // the copy of the top of the tree that references with kRefTopBit index: in HBM, or (k_extend_top) in LDS
+    DEV explicit HbmStore(const SceneDev &s) : S(s), top(reinterpret_cast<HbmNodePtr>(s.top_nodes)) {}
+    DEV HbmStore(const SceneDev &s, TopPtr top_copy) : S(s), top(top_copy) {}
     DEV uint32_t root() const { return S.root_ref; }
+    // the first 32 bytes of the node and its exit link for octant `oct`
+    DEV void fetch(uint32_t ref, uint32_t oct, uint4 &n0, uint4 &n1, uint32_t &exit_ref) const {
+        const uint32_t idx = ref & kRefIndexMask;
+        if (ref & kRefTopBit) {
+            n0 = load4(top, idx * 4u); n1 = load4(top, idx * 4u + 1u);
+            const uint4 links = load4(top, idx * 4u + 2u + (oct >> 2));
+            const uint32_t k = oct & 3u;
+            exit_ref = k == 0u ? links.x : (k == 1u ? links.y : (k == 2u ? links.z : links.w));
+        } else {
+            n0 = S.nodes[idx * 4u]; n1 = S.nodes[idx * 4u + 1u];
+            exit_ref = reinterpret_cast<const uint32_t *>(S.nodes)[idx * kNodeWords + 8u + oct];
+        }
+    }
     DEV bool uniform_times() const { return MOVING && (S.flags & kSceneUniformTimes); }
     // bx, by, bz: per axis the (near, far) planes of the node's box for this ray (acceleration.rs:66-71)
     DEV void inner(uint32_t cur, const RayCtx &r, f32x2 &bx, f32x2 &by, f32x2 &bz, uint32_t &near_ref, uint32_t &exit_ref) const {
         const uint32_t oct = r.oct;
-        const uint32_t idx = cur & kRefIndexMask;
-        const uint4 n0 = S.nodes[idx * 4u];
-        const uint4 n1 = S.nodes[idx * 4u + 1u];
-        exit_ref = reinterpret_cast<const uint32_t *>(S.nodes)[idx * kNodeWords + 8u + oct];
+        uint4 n0, n1;
+        fetch(cur, oct, n0, n1, exit_ref);
         const bool ngx = oct & 1u, ngy = oct & 2u, ngz = oct & 4u;
         bx = ngx ? f32x2{u2f(n0.y), u2f(n0.x)} : f32x2{u2f(n0.x), u2f(n0.y)};
         by = ngy ? f32x2{u2f(n0.w), u2f(n0.z)} : f32x2{u2f(n0.z), u2f(n0.w)};
         bz = ngz ? f32x2{u2f(n1.y), u2f(n1.x)} : f32x2{u2f(n1.x), u2f(n1.y)};
         const uint32_t axis = (n1.z >> RRT_NODE_AXIS_SHIFT) & 3u;
-        near_ref = ((oct >> axis) & 1u) ? (n1.z & (kRefLeafBit | kRefIndexMask)) : n1.w;  // acceleration.rs:253-267
+        near_ref = ((oct >> axis) & 1u) ? (n1.z & kRefMask) : n1.w;  // acceleration.rs:253-267
     }
     DEV void leaf(uint32_t cur, const RayCtx &r, V3 &c, float &rr, uint32_t &handle, uint32_t &exit_ref) const {
-        const uint32_t idx = cur & kRefIndexMask;
-        const uint4 n0 = S.nodes[idx * 4u];
-        const uint4 n1 = S.nodes[idx * 4u + 1u];
-        exit_ref = reinterpret_cast<const uint32_t *>(S.nodes)[idx * kNodeWords + 8u + r.oct];
+        uint4 n0, n1;
+        fetch(cur, r.oct, n0, n1, exit_ref);
         c = mk(u2f(n0.x), u2f(n0.y), u2f(n0.z));
         rr = u2f(n0.w);
         handle = n1.x;  // sphere index | material kind << 30
@@ -463,6 +480,30 @@ __global__ __launch_bounds__(kLdsBlockThreads, 8) void k_extend_lds(SceneDev S, 
     const bool pooled = total == n_lists * kWaveSlots;
     const LdsStore<MOVING> st(lds4, S.small_root);
     extend_wave<LdsStore<MOVING>, MOVING, COUNT>(st, S, P, wave, lane, retire_min, leaf_min, wave_stats, own_count, pooled ? &pool[0] : nullptr,
+                                                 wave0 * kWaveSlots, total);
+}
+
+// Scenes whose nodes stay in HBM: the top levels of the tree (every ray starts there) are walked in an LDS copy.
+template <bool MOVING, bool COUNT>
+__global__ __launch_bounds__(kLdsBlockThreads, 8) void k_extend_top(SceneDev S, PathState P, uint32_t retire_min, uint32_t leaf_min,
+                                                                  uint64_t *wave_stats) {
+    extern __shared__ uint4 lds4[];
+    __shared__ uint32_t pool[2];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave0 = P.wave_begin + blockIdx.x * (kLdsBlockThreads / 64u);
+    const uint32_t wave = wave0 + (threadIdx.x >> 6);
+    const uint32_t own_count = wave < P.wave_end ? rfl(P.qcount[wave]) : 0u;
+    if (threadIdx.x < 2) pool[threadIdx.x] = 0u;
+    for (uint32_t i = threadIdx.x; i < S.n_top * 4u; i += kLdsBlockThreads) lds4[i] = S.top_nodes[i];
+    __syncthreads();
+    if (lane == 0 && own_count) atomicAdd(&pool[1], own_count);
+    __syncthreads();
+    if (wave >= P.wave_end) return;
+    const uint32_t n_lists = min(kLdsBlockThreads / 64u, P.wave_end - wave0);
+    const uint32_t total = pool[1];
+    const bool pooled = total == n_lists * kWaveSlots;
+    const HbmStore<MOVING, LdsNodePtr> st(S, (LdsNodePtr)lds4);
+    extend_wave<HbmStore<MOVING, LdsNodePtr>, MOVING, COUNT>(st, S, P, wave, lane, retire_min, leaf_min, wave_stats, own_count, pooled ? &pool[0] : nullptr,
                                                  wave0 * kWaveSlots, total);
 }
 
@@ -1048,6 +1089,19 @@ void launch_extend(hipStream_t s, const SceneDev &S, const PathState &P, bool mo
         } else {
             if (count) hipLaunchKernelGGL((k_extend_lds<false, true>), g, b, lds, s, S, P, retire_min, leaf_min, wave_stats);
             else hipLaunchKernelGGL((k_extend_lds<false, false>), g, b, lds, s, S, P, retire_min, leaf_min, wave_stats);
+        }
+        return;
+    }
+    if (S.top_nodes && S.n_top) {
+        const uint32_t waves_per_block = kLdsBlockThreads / 64u;
+        const dim3 g((P.wave_end - P.wave_begin + waves_per_block - 1u) / waves_per_block), b(kLdsBlockThreads);
+        const size_t lds = (size_t)S.n_top * kNodeWords * 4u;
+        if (moving) {
+            if (count) hipLaunchKernelGGL((k_extend_top<true, true>), g, b, lds, s, S, P, retire_min, leaf_min, wave_stats);
+            else hipLaunchKernelGGL((k_extend_top<true, false>), g, b, lds, s, S, P, retire_min, leaf_min, wave_stats);
+        } else {
+            if (count) hipLaunchKernelGGL((k_extend_top<false, true>), g, b, lds, s, S, P, retire_min, leaf_min, wave_stats);
+            else hipLaunchKernelGGL((k_extend_top<false, false>), g, b, lds, s, S, P, retire_min, leaf_min, wave_stats);
         }
         return;
     }

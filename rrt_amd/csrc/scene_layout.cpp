@@ -104,10 +104,12 @@ int build_scene_layout(const rrt_sphere_soa *sp, const rrt_material_soa *mt, con
 
     // ---- node words ----
     out.nodes.assign(static_cast<size_t>(n_nodes) * kNodeWords, 0u);
+    out.node_kind.assign(n_nodes, 0);
     for (uint32_t i = 0; i < n_nodes; i++) {
         if (!seen[i]) continue;
         uint32_t *w = &out.nodes[static_cast<size_t>(i) * kNodeWords];
         const rrt_bvh_node &n = nodes[i];
+        out.node_kind[i] = is_leaf(n) ? 2 : 1;
         if (is_leaf(n)) {
             const uint32_t p = n.left_or_obj;
             const float r = out.sph[p].w;
@@ -175,6 +177,43 @@ int build_scene_layout(const rrt_sphere_soa *sp, const rrt_material_soa *mt, con
         out.small_root = ref14(out.root_ref);
     }
     return RRT_OK;
+}
+
+void make_top_tree(SceneLayout &L) {
+    L.top_nodes.clear();
+    if (!L.small_nodes.empty() || L.n_nodes == 0 || L.root_ref == kRefEnd) return;
+    const uint32_t none = 0xFFFFFFFFu;
+    std::vector<uint32_t> local(L.n_nodes, none);
+    std::vector<uint32_t> order, level{L.root_ref & kRefIndexMask}, next;
+    // whole levels, breadth first, while they fit
+    while (!level.empty() && order.size() + level.size() <= kTopMaxNodes) {
+        next.clear();
+        for (uint32_t i : level) {
+            local[i] = static_cast<uint32_t>(order.size());
+            order.push_back(i);
+            if (L.node_kind[i] != 1) continue;
+            const uint32_t *w = &L.nodes[static_cast<size_t>(i) * kNodeWords];
+            next.push_back(w[7] & kRefIndexMask);
+            next.push_back(w[6] & kRefIndexMask);
+        }
+        level.swap(next);
+    }
+    if (order.empty()) return;
+    auto remap = [&](uint32_t ref) -> uint32_t {
+        if (ref == kRefEnd) return ref;
+        const uint32_t at = local[ref & kRefIndexMask];
+        return at == none ? ref : ((ref & ~kRefIndexMask) | kRefTopBit | at);
+    };
+    for (uint32_t i = 0; i < L.n_nodes; i++) {
+        if (L.node_kind[i] == 0) continue;
+        uint32_t *w = &L.nodes[static_cast<size_t>(i) * kNodeWords];
+        if (L.node_kind[i] == 1) { w[6] = remap(w[6]); w[7] = remap(w[7]); }  // remap keeps the axis bits of word 6
+        for (int o = 0; o < 8; o++) w[8 + o] = remap(w[8 + o]);
+    }
+    L.root_ref = remap(L.root_ref);
+    L.top_nodes.resize(order.size() * kNodeWords);
+    for (size_t k = 0; k < order.size(); k++)
+        for (uint32_t j = 0; j < kNodeWords; j++) L.top_nodes[k * kNodeWords + j] = L.nodes[static_cast<size_t>(order[k]) * kNodeWords + j];
 }
 
 }  // namespace rrt_amd

@@ -17,7 +17,10 @@ namespace rrt_amd {
 
 constexpr uint32_t kRefLeafBit = 0x80000000u;   // a node reference that points at a leaf
 constexpr uint32_t kRefEnd = 0x7FFFFFFFu;       // "nothing left to visit"
-constexpr uint32_t kRefIndexMask = 0x1FFFFFFFu; // node index inside a reference
+constexpr uint32_t kRefIndexMask = 0x0FFFFFFFu; // node index inside a reference
+constexpr uint32_t kRefTopBit = 0x10000000u;    // the index counts inside the top-of-tree copy (make_top_tree), not the node array
+constexpr uint32_t kRefMask = kRefLeafBit | kRefTopBit | kRefIndexMask;  // a reference without the axis bits that share word 6
+constexpr uint32_t kTopMaxNodes = 1024;         // 64 KB of LDS
 constexpr uint32_t kNodeWords = 16;             // 64 bytes
 constexpr uint32_t kLeafPrimMask = 0x3FFFFFFFu; // leaf word 4: sphere index | material kind << 30
 constexpr uint32_t kLeafKindShift = 30;
@@ -46,6 +49,7 @@ struct SceneLayout {
     // [8..15] exit link per octant.  Leaf: [0..2] centre at time0, [3] radius^2, [4] sphere index | material kind << 30,
     // [5] bit 0 = moving, [8..15] exit link per octant.
     std::vector<uint32_t> nodes;
+    std::vector<uint8_t> node_kind;  // per node: 0 = not reachable from the root, 1 = inner, 2 = leaf
     uint32_t n_nodes = 0;
     uint32_t root_ref = kRefEnd;
     uint32_t max_leaf_depth = 0;
@@ -60,6 +64,10 @@ struct SceneLayout {
     uint32_t small_words = 0;
     uint32_t small_root = kRef14End;
 
+    // Top of the tree (whole levels from the root, at most kTopMaxNodes nodes) in the 64-byte node format, for scenes
+    // whose nodes stay in HBM: the extend kernel keeps this copy in LDS.  Filled by make_top_tree.
+    std::vector<uint32_t> top_nodes;
+
     std::vector<Float4> sph;        // {centre at time0, radius}
     std::vector<Float4> motion;     // {centre1 - centre0, time0}
     std::vector<float> motion_dt;   // time1 - time0
@@ -70,6 +78,10 @@ struct SceneLayout {
     uint32_t flags = 0;
     float u_time0 = 0.f, u_dt = 1.f;
 };
+
+// For a layout without a compact copy: picks the top levels of the tree, copies their nodes to `top_nodes` and rewrites
+// every reference to one of them, in `nodes`, `top_nodes` and `root_ref`, as kRefTopBit | index in `top_nodes`.
+void make_top_tree(SceneLayout &layout);
 
 // Returns RRT_OK or a negative rrt_status with a message in err.
 int build_scene_layout(const rrt_sphere_soa *spheres, const rrt_material_soa *materials, const rrt_bvh_node *nodes,
