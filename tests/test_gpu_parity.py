@@ -327,6 +327,13 @@ def test_large_scene_walks_the_hbm_bvh(gpu_ctx):
     gpu = gpu_ctx.render(rrt_amd.Context.params(nx, ny, ns, seed=6, count_work=True))
     assert_same_image(gpu, ref)
     assert gpu[2]["inner_visits"] == ref[2]["inner_visits"] and gpu[2]["leaf_tests"] == ref[2]["leaf_tests"]
+    # Bvh::hit alone on the same scene: the walk starts in the copy of the top of the tree and continues in the node array
+    idx = np.arange(nx * ny, dtype=np.uint32)
+    rays, _ = osc.gen_primary(nx, ny, 11, idx, np.zeros(nx * ny, np.uint32))
+    t_o, obj_o, _, _, _ = osc.hit_rays(rays[:, 0:3], rays[:, 3:6], rays[:, 6])
+    t_g, obj_g = gpu_ctx.intersect(rays[:, 0:3], rays[:, 3:6], rays[:, 6])
+    assert np.array_equal(obj_g, obj_o) and np.array_equal(bits(t_g), bits(t_o))
+    assert (obj_o != 0xFFFFFFFF).sum() > 100
 
 
 def test_million_sphere_scene_spot(gpu_ctx):
