@@ -367,3 +367,25 @@ def test_cli_renders_the_reference_default_scene(gpu_ctx, tmp_path):
     hs = rrt_amd.HostScene(rrt_amd.SCENE_BOOK2CHAP2, nx, ny, seed=seed)
     px, _, _ = hs.tracescene(ns, device=0)
     assert np.array_equal(np.frombuffer(raw[len(header):], np.uint8).reshape(ny, nx, 3), px)
+
+
+@pytest.mark.parametrize("name", ["chap12_1200x800x500", "book2chap2_1200x800x100"])
+def test_full_size_image_digests(gpu_ctx, name):
+    """Whole images at the headline sizes against digests of the oracle's renders (tests/golden/make_fullsize.py):
+    every pixel of every row, f32 sums and RGB8, and the ray count."""
+    import hashlib
+    import json
+    import zlib
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize.json")) as f:
+        g = json.load(f)[name]
+    nx, ny, ns = g["nx"], g["ny"], g["ns"]
+    hs = rrt_amd.HostScene(g["kind"], nx, ny, seed=g["scene_seed"])
+    gpu_ctx.upload_host_scene(hs)
+    rgb, acc, st = gpu_ctx.render(rrt_amd.Context.params(nx, ny, ns, seed=g["seed"], max_depth=g["max_depth"]))
+    acc = np.ascontiguousarray(acc.reshape(ny, nx, 3), np.float32)
+    rows = [zlib.crc32(acc[y].tobytes()) for y in range(ny)]
+    bad = [y for y in range(ny) if rows[y] != g["row_crc32"][y]]
+    assert not bad, f"{len(bad)} of {ny} rows of f32 sums differ, first: {bad[:8]}"
+    assert hashlib.sha256(acc.tobytes()).hexdigest() == g["sha256_acc"]
+    assert hashlib.sha256(np.ascontiguousarray(rgb.reshape(ny, nx, 3), np.uint8).tobytes()).hexdigest() == g["sha256_rgb"]
+    assert st["rays"] == g["counters"]["rays"] and st["paths"] == nx * ny * ns
