@@ -264,7 +264,7 @@ class Context:
         p.nx, p.ny, p.ns, p.max_depth, p.seed = nx, ny, ns, max_depth, seed
         p.shard_mode, p.shard_rank, p.shard_world = shard_mode, rank, world
         p.count_work, p.path_slots, p.batch_samples = int(count_work), path_slots, batch_samples
-        p.reserved[0] = int(time_kernels)
+        p.reserved[0] = int(time_kernels)  # True/1: every extend launch timed; n: every n-th (n in 1, 2, 4, 8)
         p.reserved[1] = int(force_hbm_bvh)
         p.reserved[2] = int(retire_min)
         p.reserved[3] = int(leaf_min)

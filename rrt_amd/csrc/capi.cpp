@@ -266,7 +266,9 @@ int render_impl(rrt_ctx *c, const rrt_render_params *pp, void *d_rgb8, void *d_a
     const uint32_t leaf_min = P.reserved[3] ? std::min<uint32_t>(P.reserved[3], 64u) : 16u;
     SceneDev sd = c->sd;
     if (P.reserved[1] & 1u) sd.small_nodes = nullptr;  // walk the HBM copy of the BVH even if the scene fits in LDS
-    const bool time_kernels = count || P.reserved[0] != 0;
+    // reserved[0] = n: HIP events around every n-th extend launch of each part (n divides the rounds of a chunk, so the
+    // timed launches are an even 1-in-n sample); the counting build times every launch
+    const uint32_t time_stride = count ? 1u : (P.reserved[0] <= kChunk && P.reserved[0] != 0 && kChunk % P.reserved[0] == 0 ? P.reserved[0] : (P.reserved[0] ? 1u : 0u));
     if (npix > 0 && ns_local > 0) {
         // ---- batch and slot sizing ----
         uint32_t batch = P.batch_samples ? P.batch_samples : (uint32_t)std::max<size_t>(1, kRadBudgetBytes / ((size_t)npix * 16));
@@ -337,6 +339,7 @@ int render_impl(rrt_ctx *c, const rrt_render_params *pp, void *d_rgb8, void *d_a
                 for (uint32_t it = 0; it < kChunk; it++) {
                     for (uint32_t h = 0; h < n_parts; h++) {
                         hipStream_t sp = part_stream[h];
+                        const bool time_kernels = time_stride != 0 && it % time_stride == 0;
                         if (time_kernels) {
                             while (c->kev.size() < kev_used + 2) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); c->kev.push_back(ev); }
                             HIP_TRY(hipEventRecord(c->kev[kev_used], sp));
