@@ -128,23 +128,27 @@ int build_scene_layout(const rrt_sphere_soa *sp, const rrt_material_soa *mt, con
 
     // ---- exit links: for octant o, the order of acceleration.rs:253-267 is fixed, so the node popped after a
     //      subtree is known ahead of time.  near = right when the ray is negative along the node's axis. ----
-    struct Link { uint32_t node, exit_ref; };
+    //      One walk carries the links of all eight octants: a child that is visited first ("near") in octant o exits to
+    //      its sibling, the other one inherits its parent's exit.
+    struct Link { uint32_t node; uint32_t exit_ref[8]; };
     std::vector<Link> ls;
-    for (uint32_t oct = 0; oct < 8; oct++) {
-        ls.clear();
-        ls.push_back({0u, kRefEnd});
-        while (!ls.empty()) {
-            Link l = ls.back(); ls.pop_back();
-            out.nodes[static_cast<size_t>(l.node) * kNodeWords + 8 + oct] = l.exit_ref;
-            const rrt_bvh_node &n = nodes[l.node];
-            if (is_leaf(n)) continue;
-            const uint32_t axis = (n.right_axis_leaf >> RRT_NODE_AXIS_SHIFT) & 3u;
-            const uint32_t left = n.left_or_obj, right = n.right_axis_leaf & RRT_NODE_INDEX_MASK;
-            const bool neg = (oct >> axis) & 1u;
-            const uint32_t near_i = neg ? right : left, far_i = neg ? left : right;
-            ls.push_back({far_i, l.exit_ref});
-            ls.push_back({near_i, ref_of(far_i)});
+    ls.push_back(Link{0u, {kRefEnd, kRefEnd, kRefEnd, kRefEnd, kRefEnd, kRefEnd, kRefEnd, kRefEnd}});
+    while (!ls.empty()) {
+        const Link l = ls.back(); ls.pop_back();
+        uint32_t *w = &out.nodes[static_cast<size_t>(l.node) * kNodeWords + 8];
+        for (uint32_t oct = 0; oct < 8; oct++) w[oct] = l.exit_ref[oct];
+        const rrt_bvh_node &n = nodes[l.node];
+        if (is_leaf(n)) continue;
+        const uint32_t axis = (n.right_axis_leaf >> RRT_NODE_AXIS_SHIFT) & 3u;
+        const uint32_t left = n.left_or_obj, right = n.right_axis_leaf & RRT_NODE_INDEX_MASK;
+        Link ll{left, {}}, lr{right, {}};
+        for (uint32_t oct = 0; oct < 8; oct++) {
+            const bool neg = (oct >> axis) & 1u;  // near = right when the ray is negative along the node's axis
+            ll.exit_ref[oct] = neg ? l.exit_ref[oct] : ref_of(right);
+            lr.exit_ref[oct] = neg ? ref_of(left) : l.exit_ref[oct];
         }
+        ls.push_back(lr);
+        ls.push_back(ll);
     }
 
     // ---- compact copy for LDS residency (layout in scene_layout.h) ----
