@@ -139,6 +139,7 @@ struct RayCtx {
     // for the compact LDS nodes: byte offset inside a node of the (near, far) plane pair of each axis, and a word whose
     // 5-bit field at 5 * axis (repeated 16 bits up) is the bit position of the near child's reference in node word 9
     uint32_t cx, cy, cz, sel;
+    uint32_t lds_base, oct2;  // set by LdsStore::prepare
     uint32_t best;  // store-specific handle of the closest leaf so far
 };
 
@@ -225,6 +226,7 @@ struct HbmStore {
             c = add(c, scale(f, mk(m.x, m.y, m.z)));
         }
     }
+    DEV void prepare(RayCtx &) const {}
     DEV uint32_t prim_of(uint32_t handle) const { return handle; }
 };
 
@@ -238,14 +240,31 @@ struct LdsStore {
     DEV bool uniform_times() const { return MOVING; }  // the compact copy exists only for scenes with one shutter interval
     // a reference is the node's offset in 8-byte units (bit 13: leaf)
     DEV const char *node_at(uint32_t off8) const { return lds + (off8 << 3); }
-    DEV static f32x2 pair_at(const char *p) { const float *f = reinterpret_cast<const float *>(p); return f32x2{f[0], f[1]}; }
+    typedef const __attribute__((address_space(3))) uint32_t *LdsWordPtr;
+    DEV static uint32_t lshl3_add(uint32_t a, uint32_t b) {
+        uint32_t r;
+        asm("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(r) : "v"(a), "v"(b));
+        return r;
+    }
+    DEV static f32x2 pair_at(uint32_t lds_addr) {
+        const __attribute__((address_space(3))) float *f = reinterpret_cast<const __attribute__((address_space(3))) float *>(static_cast<uintptr_t>(lds_addr));
+        return f32x2{f[0], f[1]};
+    }
+    // folds the LDS address of the node array into the per-ray byte offsets inner() adds to a node reference
+    DEV void prepare(RayCtx &r) const {
+        const uint32_t base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) char *)lds));
+        r.cx += base; r.cy += base; r.cz += base; r.lds_base = base; r.oct2 = base + 2u * r.oct;
+    }
     // The box is stored per axis as (min, max, min): the pair that starts one word in is (max, min), so a ray that is
     // negative along the axis reads (near, far) directly, with an address instead of a select.
     DEV void inner(uint32_t cur, const RayCtx &r, f32x2 &bx, f32x2 &by, f32x2 &bz, uint32_t &near_ref, uint32_t &exit_ref) const {
-        const uint32_t off = cur << 3;
-        bx = pair_at(lds + (off + r.cx)); by = pair_at(lds + (off + r.cy)); bz = pair_at(lds + (off + r.cz));
-        const uint32_t w9 = *reinterpret_cast<const uint32_t *>(lds + off + 36u);
-        exit_ref = *reinterpret_cast<const uint16_t *>(lds + (off + 2u * r.oct) + 40u);
+        // five LDS addresses, each one shift-and-add from the reference (prepare() has put the LDS address of the node
+        // array into the ray's offsets)
+        const uint32_t ax = lshl3_add(cur, r.cx), ay = lshl3_add(cur, r.cy), az = lshl3_add(cur, r.cz);
+        const uint32_t aw = lshl3_add(cur, r.lds_base), ae = lshl3_add(cur, r.oct2);
+        bx = pair_at(ax); by = pair_at(ay); bz = pair_at(az);
+        const uint32_t w9 = *reinterpret_cast<LdsWordPtr>(static_cast<uintptr_t>(aw + 36u));
+        exit_ref = *reinterpret_cast<const __attribute__((address_space(3))) uint16_t *>(static_cast<uintptr_t>(ae + 40u));
         // word 9 = 5 * axis | left << 4 | right << 18; only the low five bits of a shift count (v_bfe_u32) count
         const uint32_t at = __builtin_amdgcn_ubfe(r.sel, w9, 5u);
         near_ref = __builtin_amdgcn_ubfe(w9, at, kRef14Bits);
@@ -397,6 +416,7 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
             if (take) {
                 slot = n_slot;
                 ray_load(r, nA, nB, nC, 0.001f, __FLT_MAX__, S, uniform_times);  // lib.rs:57
+                st.prepare(r);
                 cur = st.root();
                 has = true;
             }
@@ -463,7 +483,9 @@ __global__ __launch_bounds__(kLdsBlockThreads, 8) void k_extend_lds(SceneDev S, 
                                                                   uint64_t *wave_stats) {
     extern __shared__ uint4 lds4[];
     const uint32_t n_vec = S.n_nodes * (kSmallWords / 2u);
-    __shared__ uint32_t pool[2];  // next position of the workgroup's ray pool; sum of the workgroup's list lengths
+    // next position of the workgroup's ray pool; sum of the workgroup's list lengths.  Behind the nodes, so that the nodes
+    // start at LDS address 0 and a node reference needs no base added
+    uint32_t *pool = reinterpret_cast<uint32_t *>(lds4) + ((n_vec * 2u + 3u) & ~3u);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave0 = P.wave_begin + blockIdx.x * (kLdsBlockThreads / 64u);
     const uint32_t wave = wave0 + (threadIdx.x >> 6);
@@ -1082,7 +1104,7 @@ void launch_extend(hipStream_t s, const SceneDev &S, const PathState &P, bool mo
     if (S.small_nodes) {  // scene fits in LDS
         const uint32_t waves_per_block = kLdsBlockThreads / 64u;
         const dim3 g((P.wave_end - P.wave_begin + waves_per_block - 1u) / waves_per_block), b(kLdsBlockThreads);
-        const size_t lds = (size_t)S.n_nodes * S.small_words * 4u;
+        const size_t lds = (((size_t)S.n_nodes * S.small_words * 4u + 15u) & ~(size_t)15u) + 16u;  // nodes, then the pool counters
         if (moving) {
             if (count) hipLaunchKernelGGL((k_extend_lds<true, true>), g, b, lds, s, S, P, retire_min, leaf_min, wave_stats);
             else hipLaunchKernelGGL((k_extend_lds<true, false>), g, b, lds, s, S, P, retire_min, leaf_min, wave_stats);
