@@ -191,6 +191,12 @@ RRT_API int rrt_debug_layout(const rrt_sphere_soa *spheres, const rrt_material_s
  * enumerates them; out_idx may be null to query the count.  With mode NONE / SAMPLE: all nx*ny pixels. */
 RRT_API uint32_t rrt_shard_pixels(uint32_t nx, uint32_t ny, uint32_t shard_mode, uint32_t rank, uint32_t world, uint32_t *out_idx);
 
+/* Bvh::build with BvhPartitionMethod::Middle (src/acceleration.rs:131-217; scene.rs:33-35 build_bvh) on the context's
+ * GPU: the same 2n-1 nodes, in the same order and with the same bits, as the reference's recursive builder makes of
+ * objects 0..n-1 (what rrt_upload_scene takes as `nodes`).  Sphere planes and out_nodes are host memory; `capacity` must
+ * be at least 2n-1.  Blocking. */
+RRT_API int rrt_build_bvh(rrt_ctx *ctx, const rrt_sphere_soa *spheres, rrt_bvh_node *out_nodes, uint32_t capacity, uint32_t *n_nodes);
+
 /* Name, compute units and HBM bytes of the context's device. */
 RRT_API int rrt_device_info(rrt_ctx *ctx, char *name, size_t name_len, int *compute_units, uint64_t *hbm_bytes);
 

@@ -15,6 +15,10 @@
 
 using namespace rrt_amd;
 
+namespace rrt_amd {
+int gpu_build_bvh(hipStream_t st, const rrt_sphere_soa *sp, rrt_bvh_node *out_nodes, uint32_t capacity, uint32_t *n_nodes, std::string &err);
+}
+
 namespace {
 
 thread_local std::string g_err;
@@ -392,6 +396,18 @@ int render_impl(rrt_ctx *c, const rrt_render_params *pp, void *d_rgb8, void *d_a
 }  // namespace
 
 extern "C" {
+
+int rrt_build_bvh(rrt_ctx *c, const rrt_sphere_soa *sp, rrt_bvh_node *out_nodes, uint32_t capacity, uint32_t *n_nodes) {
+    if (!c || !sp || !out_nodes || !n_nodes) return fail(RRT_ERR_INVALID_ARGUMENT, "rrt_build_bvh: null argument");
+    if (sp->n == 0) return fail(RRT_ERR_BAD_SCENE, "rrt_build_bvh: no objects (Bvh::build of an empty scene yields no nodes)");
+    if (sp->n > RRT_NODE_INDEX_MASK / 2u) return fail(RRT_ERR_BAD_SCENE, "rrt_build_bvh: too many objects");
+    if (!sp->c0x || !sp->c0y || !sp->c0z || !sp->c1x || !sp->c1y || !sp->c1z || !sp->radius)
+        return fail(RRT_ERR_INVALID_ARGUMENT, "rrt_build_bvh: null sphere plane");
+    HIP_TRY(hipSetDevice(c->device));
+    std::string err;
+    const int rc = rrt_amd::gpu_build_bvh(c->stream, sp, out_nodes, capacity, n_nodes, err);
+    return rc == RRT_OK ? rc : fail(rc, err);
+}
 
 int rrt_render_device(rrt_ctx *c, const rrt_render_params *p, void *d_rgb8, void *d_accum, rrt_stats *stats) {
     return render_impl(c, p, d_rgb8, d_accum, stats);

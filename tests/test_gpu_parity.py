@@ -389,3 +389,43 @@ def test_full_size_image_digests(gpu_ctx, name):
     assert hashlib.sha256(acc.tobytes()).hexdigest() == g["sha256_acc"]
     assert hashlib.sha256(np.ascontiguousarray(rgb.reshape(ny, nx, 3), np.uint8).tobytes()).hexdigest() == g["sha256_rgb"]
     assert st["rays"] == g["counters"]["rays"] and st["paths"] == nx * ny * ns
+
+
+@pytest.mark.parametrize("kind,half", [(rrt_amd.SCENE_CHAP11, 0), (rrt_amd.SCENE_CHAP12, 0), (rrt_amd.SCENE_BOOK2CHAP2, 0),
+                                       (rrt_amd.SCENE_RANDOM_SPHERES, 60), (rrt_amd.SCENE_RANDOM_SPHERES, 500)])
+def test_gpu_bvh_build_is_the_reference_tree(gpu_ctx, kind, half):
+    """rrt_build_bvh (level-synchronous, on the device) against the recursive host builder that mirrors Bvh::build_r:
+    every node, every bit.  chap11 takes the equal-count fallback (two concentric spheres), book2chap2 has moving boxes."""
+    hs = rrt_amd.HostScene(kind, 64, 64, seed=0, half=max(half, 11))
+    sp, mt, nd, cam = hs.export()
+    got = gpu_ctx.build_bvh(sp)
+    assert got.shape == nd.shape
+    assert np.array_equal(got, nd), f"{int((got != nd).any(axis=1).sum())} of {nd.shape[0]} nodes differ"
+
+
+def test_gpu_bvh_build_degenerate_inputs(gpu_ctx):
+    """One object, two objects at one place, many identical centroids (equal-count all the way down), negative radius."""
+    rng = np.random.default_rng(3)
+    cases = []
+    one = np.zeros((1, 9), np.float32); one[0, 8] = 1.0
+    cases.append(one)
+    two = np.zeros((2, 9), np.float32); two[:, 8] = [0.5, -0.45]; two[:, 7] = 1.0
+    cases.append(two)
+    same = np.zeros((37, 9), np.float32); same[:, 0:3] = [1.0, 2.0, 3.0]; same[:, 3:6] = [1.0, 2.0, 3.0]; same[:, 7] = 1.0
+    same[:, 8] = rng.uniform(0.1, 1.0, 37)
+    cases.append(same)
+    mixed = np.zeros((300, 9), np.float32)
+    mixed[:, 0:3] = rng.integers(-3, 4, (300, 3))       # many repeated centres: fallbacks at several depths
+    mixed[:, 3:6] = mixed[:, 0:3]
+    mixed[:, 7] = 1.0
+    mixed[:, 8] = 0.25
+    cases.append(mixed)
+    from oracle import OracleScene as O
+    for sp in cases:
+        n = sp.shape[0]
+        mt = np.zeros((n, 6), np.float32); mt[:, 1:4] = 0.5
+        osc = O.from_arrays(sp, np.arange(n, dtype=np.uint32), mt, np.zeros((1, 8), np.uint32))
+        osc.build_bvh(0)
+        _, _, nd, _ = osc.export()
+        got = gpu_ctx.build_bvh(sp)
+        assert got.shape == nd.shape and np.array_equal(got, nd), f"n={n}: {int((got != nd).any(axis=1).sum())} nodes differ"
