@@ -337,7 +337,7 @@ def test_large_scene_walks_the_hbm_bvh(gpu_ctx):
 
 
 def test_million_sphere_scene_spot(gpu_ctx):
-    """BASELINE configs[4] shape: 1000x1000 cells (~1 M spheres, ~2 M nodes), 1920x1080; spot-checked pixels at 8 spp."""
+    """The big-scene configuration: 1000x1000 cells (~1 M spheres, ~2 M nodes), 1920x1080; spot-checked pixels at 8 spp."""
     nx, ny, ns, half = 1920, 1080, 8, 500
     hs = rrt_amd.HostScene(rrt_amd.SCENE_RANDOM_SPHERES, nx, ny, seed=0, half=half)
     assert hs.n_spheres > 990000
