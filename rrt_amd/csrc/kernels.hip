@@ -425,9 +425,17 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
             if (__ballot(has) == 0ull) break;
         }
         // descend until no lane is at an inner node, or enough lanes wait at a sphere for a test to be worth a pass
-        for (;;) {
-            const bool at_inner = cur < Store::kEnd;
-            const uint64_t im = __ballot(at_inner);
+        for (;;) {  // two box tests per look at the number of lanes waiting at a sphere
+            bool at_inner = cur < Store::kEnd;
+            uint64_t im = __ballot(at_inner);
+            if (im == 0ull) break;
+            if (COUNT) { d_desc_iters++; d_desc_lanes += (uint32_t)__popcll(im); }
+            if (at_inner) {
+                if (COUNT) n_inner++;
+                cur = visit_inner(st, cur, r);
+            }
+            at_inner = cur < Store::kEnd;
+            im = __ballot(at_inner);
             if (im == 0ull) break;
             if (COUNT) { d_desc_iters++; d_desc_lanes += (uint32_t)__popcll(im); }
             if (at_inner) {
