@@ -407,14 +407,13 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
                 n_slot = col == 0u ? s0 : (col == 1u ? s1 : (col == 2u ? s2 : s3));
             }
             const bool take = idle && pos < count;
-            float4 nA = make_float4(0, 0, 0, 0), nB = nA, nC = nA;
-            if (take) { nA = P.rayA[n_slot]; nB = P.rayB[n_slot]; nC = P.rayC[n_slot]; }
             if (idle && has) {
                 P.hit[slot] = make_uint2(f2u(r.tmax), r.best == kPrimNone ? kPrimNone : st.prim_of(r.best));
                 has = false;
             }
             if (take) {
                 slot = n_slot;
+                const float4 nA = P.rayA[n_slot], nB = P.rayB[n_slot], nC = P.rayC[n_slot];
                 ray_load(r, nA, nB, nC, 0.001f, __FLT_MAX__, S, uniform_times);  // lib.rs:57
                 st.prepare(r);
                 cur = st.root();
