@@ -476,7 +476,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_extend(SceneDev S, PathState 
     __syncthreads();
     if (wave >= P.wave_end) return;
     const uint32_t n_lists = min(kBlockThreads / 64u, P.wave_end - wave0);
-    const uint32_t total = pool[1];
+    const uint32_t total = rfl(pool[1]);  // the same for every lane: say so, and the list bookkeeping stays in scalar registers
     const bool pooled = total == n_lists * kWaveSlots;
     const HbmStore<MOVING> st(S);
     extend_wave<HbmStore<MOVING>, MOVING, COUNT>(st, S, P, wave, lane, retire_min, leaf_min, wave_stats, own_count, pooled ? &pool[0] : nullptr,
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(kLdsBlockThreads, 8) void k_extend_lds(SceneDev S, 
     __syncthreads();
     if (wave >= P.wave_end) return;
     const uint32_t n_lists = min(kLdsBlockThreads / 64u, P.wave_end - wave0);
-    const uint32_t total = pool[1];
+    const uint32_t total = rfl(pool[1]);  // the same for every lane: say so, and the list bookkeeping stays in scalar registers
     const bool pooled = total == n_lists * kWaveSlots;
     const LdsStore<MOVING> st(lds4, S.small_root);
     extend_wave<LdsStore<MOVING>, MOVING, COUNT>(st, S, P, wave, lane, retire_min, leaf_min, wave_stats, own_count, pooled ? &pool[0] : nullptr,
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(kLdsBlockThreads, 8) void k_extend_top(SceneDev S, 
     __syncthreads();
     if (wave >= P.wave_end) return;
     const uint32_t n_lists = min(kLdsBlockThreads / 64u, P.wave_end - wave0);
-    const uint32_t total = pool[1];
+    const uint32_t total = rfl(pool[1]);  // the same for every lane: say so, and the list bookkeeping stays in scalar registers
     const bool pooled = total == n_lists * kWaveSlots;
     const HbmStore<MOVING, LdsNodePtr> st(S, (LdsNodePtr)lds4);
     extend_wave<HbmStore<MOVING, LdsNodePtr>, MOVING, COUNT>(st, S, P, wave, lane, retire_min, leaf_min, wave_stats, own_count, pooled ? &pool[0] : nullptr,
