@@ -933,8 +933,8 @@ __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads) void k
     // New paths for the slots whose path ends are generated 64 at a time with every lane busy (lane i makes the path of
     // the wave's ending slot gen_first + i) and stay in registers; the lane that owns an ending slot fetches its path
     // from there (ds_bpermute) when its tile comes up.
-    NewPath gen;
-    gen.A = gen.B = make_float4(0.0f, 0.0f, 0.0f, 0.0f); gen.rng = make_uint4(0u, 0u, 0u, 0u); gen.ok = false;
+    NewPath gen;  // ray and generator state are meaningful only where .ok is set
+    gen.ok = false;
     uint32_t gen_first = 0, gen_end = 0;  // ending slots [gen_first, gen_end) are in `gen`
 #pragma unroll
     for (uint32_t t = 0; t < 4u; t++) {
@@ -948,8 +948,9 @@ __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads) void k
             const uint64_t end_m = __ballot(ending);
             const uint32_t end_rank = end_before[t] + (uint32_t)__popcll(end_m & lt_mask);
             const uint32_t end_hi = end_before[t] + (uint32_t)__popcll(end_m);
-            NewPath np;
-            np.A = np.B = make_float4(0.0f, 0.0f, 0.0f, 0.0f); np.rng = make_uint4(0u, 0u, 0u, 0u); np.ok = false;
+            NewPath np;  // read by the lanes of ending slots only, and those always fetch one below
+            np.ok = false;
+            bool first_fetch = true;
             for (uint32_t have = end_before[t]; have < end_hi;) {
                 if (gen_end <= have) {  // generate the next 64
                     gen_first = gen_end;
@@ -965,7 +966,9 @@ __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads) void k
                 const int src = (int)((end_rank - gen_first) & 63u);
                 const bool mine = ending && end_rank >= have && end_rank < gen_end;
                 const NewPath got = fetch_path(gen, src);
-                if (mine) np = got;
+                if (first_fetch) np = got;  // lanes it is not meant for overwrite it in the next round, or never look at it
+                else if (mine) np = got;
+                first_fetch = false;
                 have = min(gen_end, end_hi);
             }
             if (pos < count) shade_slot<MOVING, Tables>(S, T, P, Bt, cls, sq[t], buf[t & 1u], l_ent[pos], np, alive, absorbed, started);
