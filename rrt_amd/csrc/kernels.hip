@@ -349,10 +349,10 @@ DEV uint64_t wave_sum_u64(uint64_t v) {
     return v;
 }
 
-// One wave's share of an extend launch.  The wave's live-slot list is a pool of rays: whenever lanes finish their ray
-// they are given the next rays of the list (the list itself is read up front, one column per lane).  Inside a ray the walk alternates "descend through inner nodes" and "test one
-// sphere" (the latter once `leaf_min` lanes wait for it), so that lanes run the same kind of step together.  Finished
-// lanes wait until at least `retire_min` of them can be retired and restarted in one go (or nothing else is left).
+// One wave's share of an extend launch.  Rays come from a pool (below): whenever lanes finish their ray they are given
+// the next rays of the pool.  Inside a ray the walk alternates "descend through inner nodes" and "test one sphere" (the
+// latter once `leaf_min` lanes wait for it), so that lanes run the same kind of step together.  Finished lanes wait
+// until at least `retire_min` of them can be retired and restarted in one go (or nothing else is left).
 template <class Store, bool MOVING, bool COUNT>
 DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uint32_t wave, uint32_t lane, uint32_t retire_min,
                      uint32_t leaf_min, uint64_t *wave_stats, uint32_t own_count, uint32_t *pool_head, uint32_t pool_base, uint32_t pool_total) {
@@ -368,7 +368,7 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
     const bool uniform_times = st.uniform_times();
     uint32_t n_inner = 0, n_leaf = 0;
     uint32_t d_desc_iters = 0, d_desc_lanes = 0, d_leaf_iters = 0, d_leaf_lanes = 0, d_retires = 0, d_retire_lanes = 0;  // COUNT only
-    // the lane's column of the live-slot list, read up front so that no ray load ever waits for a list load
+    // (own list that is not full) the lane's column of the list, read up front so that no ray load waits for a list load
     static_assert(kWaveSlots == 256, "four list entries per lane");
     uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;
     if (!pooled && count != kWaveSlots) {
@@ -390,7 +390,7 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
         const uint64_t ready = __ballot(idle && (has || head < count));
         if (~idle_m == 0ull || (uint32_t)__popcll(ready) >= retire_min) {
             if (COUNT) { d_retires++; d_retire_lanes += (uint32_t)__popcll(ready); }
-            // every idle lane takes the next ray of the list, in lane order; list entry p sits in lane p % 64, register p / 64
+            // every idle lane takes the next ray, in lane order
             const uint32_t n_idle = (uint32_t)__popcll(idle_m);
             if (pooled && head < count) {  // `head` doubles as "the pool is not known to be empty"
                 uint32_t got = 0;
@@ -398,8 +398,8 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
                 head = min(rfl(got), count);
             }
             const uint32_t pos = head + (uint32_t)__popcll(idle_m & lt_mask);
-            uint32_t n_slot = base + pos;  // a full list is every slot of the wave, in order
-            if (!pooled && count != kWaveSlots) {
+            uint32_t n_slot = base + pos;  // the pool, or a full list, is a run of consecutive slots
+            if (!pooled && count != kWaveSlots) {  // list entry p sits in lane p % 64, register p / 64
                 const uint32_t col = pos >> 6;
                 const int src = (int)(pos & 63u);
                 const uint32_t s0 = (uint32_t)__shfl((int)q0, src, 64), s1 = (uint32_t)__shfl((int)q1, src, 64);
