@@ -1,9 +1,24 @@
 #include "scene_layout.h"
 
+#include <algorithm>
 #include <cmath>
+#include <thread>
 #include <cstring>
 
 namespace rrt_amd {
+
+namespace {
+// fn(begin, end) over [0, n) on a few host threads when the range is big enough to pay for them
+template <class Fn>
+void parallel_ranges(size_t n, Fn fn) {
+    const size_t n_threads = n < (size_t(1) << 16) ? 1 : std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency()));
+    if (n_threads == 1) { fn(size_t(0), n); return; }
+    std::vector<std::thread> pool;
+    const size_t step = (n + n_threads - 1) / n_threads;
+    for (size_t b = 0; b < n; b += step) pool.emplace_back([=] { fn(b, std::min(n, b + step)); });
+    for (std::thread &t : pool) t.join();
+}
+}  // namespace
 namespace {
 
 inline uint32_t f2u(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
@@ -105,9 +120,10 @@ int build_scene_layout(const rrt_sphere_soa *sp, const rrt_material_soa *mt, con
     // ---- node words ----
     out.nodes.assign(static_cast<size_t>(n_nodes) * kNodeWords, 0u);
     out.node_kind.assign(n_nodes, 0);
-    for (uint32_t i = 0; i < n_nodes; i++) {
+    parallel_ranges(n_nodes, [&](size_t begin, size_t end) {
+    for (size_t i = begin; i < end; i++) {
         if (!seen[i]) continue;
-        uint32_t *w = &out.nodes[static_cast<size_t>(i) * kNodeWords];
+        uint32_t *w = &out.nodes[i * kNodeWords];
         const rrt_bvh_node &n = nodes[i];
         out.node_kind[i] = is_leaf(n) ? 2 : 1;
         if (is_leaf(n)) {
@@ -124,6 +140,7 @@ int build_scene_layout(const rrt_sphere_soa *sp, const rrt_material_soa *mt, con
             w[7] = ref_of(n.left_or_obj);
         }
     }
+    });
     out.root_ref = ref_of(0);
 
     // ---- exit links: for octant o, the order of acceleration.rs:253-267 is fixed, so the node popped after a
@@ -131,9 +148,10 @@ int build_scene_layout(const rrt_sphere_soa *sp, const rrt_material_soa *mt, con
     //      One walk carries the links of all eight octants: a child that is visited first ("near") in octant o exits to
     //      its sibling, the other one inherits its parent's exit.
     struct Link { uint32_t node; uint32_t exit_ref[8]; };
-    std::vector<Link> ls;
-    ls.push_back(Link{0u, {kRefEnd, kRefEnd, kRefEnd, kRefEnd, kRefEnd, kRefEnd, kRefEnd, kRefEnd}});
-    while (!ls.empty()) {
+    // (the subtrees left on the stack once it holds a few hundred entries are disjoint: on big trees they are shared out
+    // to host threads)
+    auto walk = [&](std::vector<Link> &ls, size_t stop_at) {
+    while (!ls.empty() && ls.size() < stop_at) {
         const Link l = ls.back(); ls.pop_back();
         uint32_t *w = &out.nodes[static_cast<size_t>(l.node) * kNodeWords + 8];
         for (uint32_t oct = 0; oct < 8; oct++) w[oct] = l.exit_ref[oct];
@@ -149,6 +167,19 @@ int build_scene_layout(const rrt_sphere_soa *sp, const rrt_material_soa *mt, con
         }
         ls.push_back(lr);
         ls.push_back(ll);
+    }
+    };
+    std::vector<Link> ls;
+    ls.push_back(Link{0u, {kRefEnd, kRefEnd, kRefEnd, kRefEnd, kRefEnd, kRefEnd, kRefEnd, kRefEnd}});
+    const size_t kShareAt = 512;
+    walk(ls, n_nodes >= (1u << 16) ? kShareAt : ~size_t(0));
+    if (!ls.empty()) {
+        const size_t n_threads = std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency()));
+        std::vector<std::vector<Link>> share(n_threads);
+        for (size_t k = 0; k < ls.size(); k++) share[k % n_threads].push_back(ls[k]);
+        std::vector<std::thread> pool;
+        for (size_t t = 0; t < n_threads; t++) pool.emplace_back([&, t] { walk(share[t], ~size_t(0)); });
+        for (std::thread &t : pool) t.join();
     }
 
     // ---- compact copy for LDS residency (layout in scene_layout.h) ----
@@ -208,12 +239,14 @@ void make_top_tree(SceneLayout &L) {
         const uint32_t at = local[ref & kRefIndexMask];
         return at == none ? ref : ((ref & ~kRefIndexMask) | kRefTopBit | at);
     };
-    for (uint32_t i = 0; i < L.n_nodes; i++) {
-        if (L.node_kind[i] == 0) continue;
-        uint32_t *w = &L.nodes[static_cast<size_t>(i) * kNodeWords];
-        if (L.node_kind[i] == 1) { w[6] = remap(w[6]); w[7] = remap(w[7]); }  // remap keeps the axis bits of word 6
-        for (int o = 0; o < 8; o++) w[8 + o] = remap(w[8 + o]);
-    }
+    parallel_ranges(L.n_nodes, [&](size_t begin, size_t end) {
+        for (size_t i = begin; i < end; i++) {
+            if (L.node_kind[i] == 0) continue;
+            uint32_t *w = &L.nodes[i * kNodeWords];
+            if (L.node_kind[i] == 1) { w[6] = remap(w[6]); w[7] = remap(w[7]); }  // remap keeps the axis bits of word 6
+            for (int o = 0; o < 8; o++) w[8 + o] = remap(w[8 + o]);
+        }
+    });
     L.root_ref = remap(L.root_ref);
     L.top_nodes.resize(order.size() * kNodeWords);
     for (size_t k = 0; k < order.size(); k++)
