@@ -243,3 +243,16 @@ def test_cli_argument_handling():
     assert r.returncode == 0 and "invalid rng seed" in r.stderr
     r = subprocess.run([exe, "--bogus"], capture_output=True, text=True, timeout=20)
     assert r.returncode == 2
+
+
+def test_exit_links_on_a_tree_big_enough_for_the_threaded_layout_passes():
+    """~47 k spheres / ~94 k nodes: past the size from which the layout builder shares its passes out to host threads."""
+    hs = rrt_amd.HostScene(rrt_amd.SCENE_RANDOM_SPHERES, 64, 64, seed=1, half=110)
+    sp, mt, nd, _ = hs.export()
+    assert nd.shape[0] > (1 << 16)
+    words, root, flags = rrt_amd.debug_layout(sp, np.arange(sp.shape[0], dtype=np.uint32), mt, nd)
+    rng = np.random.default_rng(1)
+    for oct_, p in [(0, 1.0), (5, 0.6), (7, 0.85)]:
+        hits = rng.uniform(size=len(nd)) < p
+        f = lambda i: bool(hits[i])
+        assert linked_visit_order(words, root, oct_, f) == stack_visit_order(nd, oct_, f)
