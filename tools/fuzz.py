@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Randomised GPU-vs-oracle comparison: random scene, image size, sample count, depth limit, pool size, batch size, pool
+parts, every image compared bit for bit.  python tools/fuzz.py [seconds] [seed] [big]
+("big": images large enough to fill the path pool, so that the workgroup-wide hand-out of the extend kernel is in use)"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import rrt_amd
+from oracle import OracleScene
+from tests.conftest import scene_arrays_from_oracle
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+ctx = rrt_amd.Context(0)
+t_end = time.time() + budget
+big = len(sys.argv) > 3 and sys.argv[3] == "big"
+n_cases = 0
+while time.time() < t_end:
+    kind = int(rng.integers(0, 4))
+    half = int(rng.integers(3, 40)) if kind == 3 else 11
+    nx, ny = (int(rng.integers(300, 700)), int(rng.integers(200, 420))) if big else (int(rng.integers(1, 200)), int(rng.integers(1, 120)))
+    ns = int(rng.integers(4, 24)) if big else int(rng.integers(1, 20))
+    depth = int(rng.choice([0, 1, 3, 50]))
+    slots = int(rng.choice([256 * 64, 256 * 512, 256 * 1024, 256 * 4096])) if big else int(rng.choice([0, 256, 512, 4096, 256 * 33, 256 * 1024]))
+    batch = int(rng.choice([0, 1, 3, 7]))
+    parts = str(int(rng.integers(1, 5)))
+    force_hbm = bool(rng.integers(0, 2))
+    seed, scene_seed = int(rng.integers(0, 1 << 30)), int(rng.integers(0, 100))
+    os.environ["RRT_STREAMS"] = parts
+    osc = OracleScene.build(kind, nx, ny, seed=scene_seed, half=half)
+    sp, mid, mt, nd, cam21 = scene_arrays_from_oracle(osc)
+    ctx.upload_scene(sp, mid, mt, nd)
+    ctx.set_camera(rrt_amd.Camera.from_buffer_copy(cam21.tobytes()))
+    rgb_o, acc_o, ct = osc.render(nx, ny, ns, seed=seed, max_depth=depth, threads=8)
+    p = rrt_amd.Context.params(nx, ny, ns, seed=seed, max_depth=depth, path_slots=slots, batch_samples=batch, force_hbm_bvh=force_hbm,
+                               count_work=bool(rng.integers(0, 2)))
+    rgb, acc, st = ctx.render(p)
+    tag = f"kind {kind} half {half} {nx}x{ny}x{ns} depth {depth} slots {slots} batch {batch} parts {parts} hbm {force_hbm} seed {seed}/{scene_seed}"
+    ok = np.array_equal(acc.view(np.uint32), acc_o.view(np.uint32)) and np.array_equal(rgb, rgb_o) and st["rays"] == ct["rays"]
+    if not ok:
+        print("MISMATCH", tag, flush=True)
+        sys.exit(1)
+    n_cases += 1
+    if n_cases % 20 == 0: print(n_cases, "cases", flush=True)
+print(f"{n_cases} random cases, all bit-identical to the oracle", flush=True)
