@@ -429,3 +429,36 @@ def test_gpu_bvh_build_degenerate_inputs(gpu_ctx):
         _, _, nd, _ = osc.export()
         got = gpu_ctx.build_bvh(sp)
         assert got.shape == nd.shape and np.array_equal(got, nd), f"n={n}: {int((got != nd).any(axis=1).sum())} nodes differ"
+
+
+def test_device_buffer_entry_points(gpu_ctx):
+    """rrt_render_device (image left in caller-owned device memory) and rrt_finalize (quantise summed sample shards on the
+    device), as bench.py and the multi-GPU combine use them."""
+    import torch
+    from rrt_amd import multi
+    nx, ny, ns = 150, 90, 10
+    osc = OracleScene.build(SCENES["chap12"], nx, ny, seed=0)
+    upload_from_oracle(gpu_ctx, osc)
+    ref = osc.render(nx, ny, ns, seed=8, threads=8)
+    dev = torch.device("cuda", 0)
+    rgb = torch.zeros(ny * nx * 3, dtype=torch.uint8, device=dev)
+    acc = torch.zeros(ny * nx * 3, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    st = gpu_ctx.render_device(rrt_amd.Context.params(nx, ny, ns, seed=8), rgb.data_ptr(), acc.data_ptr())
+    assert_same_image((rgb.cpu().numpy().reshape(ny, nx, 3), acc.cpu().numpy().reshape(ny, nx, 3), st), ref)
+    # two sample shards, summed on the device, quantised by rrt_finalize
+    parts = []
+    for rank in range(2):
+        a = torch.zeros_like(acc)
+        torch.cuda.synchronize()
+        gpu_ctx.render_device(rrt_amd.Context.params(nx, ny, ns, seed=8, shard_mode=rrt_amd.SHARD_SAMPLE, rank=rank, world=2), 0, a.data_ptr())
+        parts.append(a)
+    total = parts[0] + parts[1]
+    out = torch.zeros_like(rgb)
+    torch.cuda.synchronize()
+    gpu_ctx.finalize(total.data_ptr(), nx * ny, ns, out.data_ptr())
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert np.array_equal(got, multi.finalize_numpy(total.cpu().numpy(), ns))   # lib.rs:105-108, bit for bit
+    diff = np.abs(got.astype(int) - ref[0].reshape(-1).astype(int))             # another order of f32 additions than one render
+    assert diff.max() <= 1 and (diff != 0).mean() < 0.01
