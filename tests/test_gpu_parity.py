@@ -462,3 +462,20 @@ def test_device_buffer_entry_points(gpu_ctx):
     assert np.array_equal(got, multi.finalize_numpy(total.cpu().numpy(), ns))   # lib.rs:105-108, bit for bit
     diff = np.abs(got.astype(int) - ref[0].reshape(-1).astype(int))             # another order of f32 additions than one render
     assert diff.max() <= 1 and (diff != 0).mean() < 0.01
+
+
+def test_build_bvh_argument_errors(gpu_ctx):
+    import ctypes as C
+    sp = np.zeros((3, 9), np.float32); sp[:, 0] = [0, 1, 2]; sp[:, 3] = [0, 1, 2]; sp[:, 8] = 0.3
+    cols = [np.ascontiguousarray(sp[:, i]) for i in range(9)]
+    mid = np.zeros(3, np.uint32)
+    s = rrt_amd.SphereSoa(*[c.ctypes.data_as(C.POINTER(C.c_float)) for c in cols], mid.ctypes.data_as(C.POINTER(C.c_uint32)), 3)
+    nodes = np.zeros((5, 8), np.uint32)
+    n = C.c_uint32(0)
+    L = rrt_amd.lib()
+    assert L.rrt_build_bvh(gpu_ctx._h, C.byref(s), nodes.ctypes.data, 4, C.byref(n)) < 0        # 2n-1 = 5 nodes do not fit 4
+    assert b"2n-1" in L.rrt_last_error()
+    assert L.rrt_build_bvh(gpu_ctx._h, C.byref(s), None, 5, C.byref(n)) < 0
+    empty = rrt_amd.SphereSoa(*[c.ctypes.data_as(C.POINTER(C.c_float)) for c in cols], mid.ctypes.data_as(C.POINTER(C.c_uint32)), 0)
+    assert L.rrt_build_bvh(gpu_ctx._h, C.byref(empty), nodes.ctypes.data, 5, C.byref(n)) < 0
+    assert L.rrt_build_bvh(gpu_ctx._h, C.byref(s), nodes.ctypes.data, 5, C.byref(n)) == 0 and n.value == 5
