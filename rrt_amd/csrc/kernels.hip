@@ -489,17 +489,16 @@ template <bool MOVING, bool COUNT>
 __global__ __launch_bounds__(kLdsBlockThreads, 8) void k_extend_lds(SceneDev S, PathState P, uint32_t retire_min, uint32_t leaf_min,
                                                                   uint64_t *wave_stats) {
     extern __shared__ uint4 lds4[];
-    const uint32_t n_vec = S.n_nodes * (kSmallWords / 2u);
+    const uint32_t n_vec = (S.n_nodes * kSmallWords + 3u) / 4u;  // 16-byte pieces; the host pads the array to a whole number of them
     // next position of the workgroup's ray pool; sum of the workgroup's list lengths.  Behind the nodes, so that the nodes
     // start at LDS address 0 and a node reference needs no base added
-    uint32_t *pool = reinterpret_cast<uint32_t *>(lds4) + ((n_vec * 2u + 3u) & ~3u);
+    uint32_t *pool = reinterpret_cast<uint32_t *>(lds4 + n_vec);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave0 = P.wave_begin + blockIdx.x * (kLdsBlockThreads / 64u);
     const uint32_t wave = wave0 + (threadIdx.x >> 6);
     const uint32_t own_count = wave < P.wave_end ? rfl(P.qcount[wave]) : 0u;
     if (threadIdx.x < 2) pool[threadIdx.x] = 0u;
-    for (uint32_t i = threadIdx.x; i < n_vec; i += kLdsBlockThreads)
-        reinterpret_cast<uint2 *>(lds4)[i] = reinterpret_cast<const uint2 *>(S.small_nodes)[i];
+    for (uint32_t i = threadIdx.x; i < n_vec; i += kLdsBlockThreads) lds4[i] = S.small_nodes[i];
     __syncthreads();
     if (lane == 0 && own_count) atomicAdd(&pool[1], own_count);
     __syncthreads();

@@ -210,6 +210,7 @@ int build_scene_layout(const rrt_sphere_soa *sp, const rrt_material_soa *mt, con
             for (int o = 0; o < 8; o += 2) s[10 + o / 2] = ref14(w[8 + o]) | (ref14(w[8 + o + 1]) << 16);
         }
         out.small_root = ref14(out.root_ref);
+        out.small_nodes.resize((out.small_nodes.size() + 3u) & ~size_t(3), 0u);  // the extend kernel copies it in 16-byte pieces
     }
     return RRT_OK;
 }
