@@ -2,7 +2,7 @@
 # hipcc cross-compiles without a GPU.  Strict floating point everywhere: no contraction, no fast-math,
 # correctly rounded f32 division and square root on the device.
 HIPCC   ?= /opt/rocm/bin/hipcc
-ARCH    ?= gfx950
+ARCH    := gfx950   # the only target: the kernels use gfx950 instructions and its 160 KiB of LDS per CU
 FPFLAGS := -ffp-contract=off -fno-fast-math
 DEVFLAGS:= --offload-arch=$(ARCH) -fhip-fp32-correctly-rounded-divide-sqrt
 CXXFLAGS:= -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wextra -Wno-unused-parameter $(FPFLAGS)

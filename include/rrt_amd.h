@@ -80,7 +80,7 @@ typedef struct rrt_bvh_node {
 
 #define RRT_NODE_LEAF_BIT 0x80000000u
 #define RRT_NODE_AXIS_SHIFT 29
-#define RRT_NODE_INDEX_MASK 0x1FFFFFFFu
+#define RRT_NODE_INDEX_MASK 0x1FFFFFFFu  /* field width of the interchange node; rrt_upload_scene takes at most 2^28-1 nodes */
 
 /* Camera (src/camera.rs:5-16) after Camera::from (src/camera.rs:31-54).  time_low / time_scale are
  * the two fields of rand's Uniform<f32> built by new_inclusive(time0, time1) (src/camera.rs:52). */
@@ -105,7 +105,8 @@ enum { RRT_SHARD_NONE = 0, RRT_SHARD_TILE = 1, RRT_SHARD_SAMPLE = 2 };
 
 typedef struct rrt_render_params {
     uint32_t nx, ny, ns;  /* lib.rs:74-76 */
-    uint32_t max_depth;   /* the literal 50 of lib.rs:58 */
+    uint32_t max_depth;   /* the literal 50 of lib.rs:58.  Taken as given: 0 is a depth limit of 0 (every hit returns black,
+                             the image is sky and black), not "library default" — set it explicitly */
     uint64_t seed;        /* base of the per-(pixel, sample) Xoshiro128Plus streams */
     uint32_t shard_mode, shard_rank, shard_world;
     uint32_t count_work;  /* non-zero: also count node visits / sphere tests / shaded hits (slower build of the same kernels) */
@@ -154,10 +155,13 @@ RRT_API int rrt_set_camera(rrt_ctx *ctx, const rrt_camera *camera);
 
 /* Replaces the body of tracescene (lib.rs:82-112).  out_rgb8: nx*ny*3 bytes, RGB interleaved, row 0
  * = top of the image (lib.rs:93-94,106-108), host memory.  out_accum (nullable): nx*ny*3 floats,
- * the per-pixel sums before the division by ns (lib.rs:95-103).  progress (nullable) is set to
- * the number of finished pixels when the call returns (lib.rs:109).  Under TILE sharding only this
- * rank's pixels are written (the rest of both buffers is zero-filled); under SAMPLE sharding
- * out_rgb8 is the image of this rank's samples alone. */
+ * the per-pixel sums before the division by ns (lib.rs:95-103).  progress (nullable) plays the part
+ * of `pdc` (lib.rs:81,109; polled by main.rs:78-94): the call zeroes it, raises it while it runs —
+ * after every few extend/shade rounds, to the number of pixels' worth of finished samples — and
+ * leaves it at the number of pixels this call rendered (nx*ny unless TILE-sharded); another thread
+ * may read it meanwhile.  Under TILE sharding only this rank's pixels are written (the rest of both
+ * buffers is zero-filled); under SAMPLE sharding out_accum holds this rank's partial sums and
+ * out_rgb8 is the image of this rank's samples alone (quantised with this rank's sample count). */
 RRT_API int rrt_render(rrt_ctx *ctx, const rrt_render_params *params, uint8_t *out_rgb8, float *out_accum,
                        rrt_stats *stats, volatile uint64_t *progress);
 
@@ -192,9 +196,11 @@ RRT_API int rrt_debug_layout(const rrt_sphere_soa *spheres, const rrt_material_s
 RRT_API uint32_t rrt_shard_pixels(uint32_t nx, uint32_t ny, uint32_t shard_mode, uint32_t rank, uint32_t world, uint32_t *out_idx);
 
 /* Bvh::build with BvhPartitionMethod::Middle (src/acceleration.rs:131-217; scene.rs:33-35 build_bvh) on the context's
- * GPU: the same 2n-1 nodes, in the same order and with the same bits, as the reference's recursive builder makes of
- * objects 0..n-1 (what rrt_upload_scene takes as `nodes`).  Sphere planes and out_nodes are host memory; `capacity` must
- * be at least 2n-1.  Blocking. */
+ * GPU: 2n-1 nodes in the reference's push order over objects 0..n-1 (what rrt_upload_scene takes as `nodes`), identical
+ * to the recursive builder's wherever its result is determined.  Where it is not — inside subtrees that fall back to
+ * the equal-count split, select_nth_unstable_by leaves the order of equal keys to the implementation — ties are
+ * resolved as a stable sort would.  Sphere planes and out_nodes are host memory; `capacity` must be at least 2n-1;
+ * n <= 2^27 (the node index space of rrt_upload_scene).  Blocking. */
 RRT_API int rrt_build_bvh(rrt_ctx *ctx, const rrt_sphere_soa *spheres, rrt_bvh_node *out_nodes, uint32_t capacity, uint32_t *n_nodes);
 
 /* Name, compute units and HBM bytes of the context's device. */

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <vector>
 
@@ -49,13 +50,40 @@ struct DevBuf {
 };
 
 constexpr uint32_t kDefaultSlots = 1u << 22;
-constexpr size_t kRadBudgetBytes = size_t(16) << 30;  // per-batch radiance planes; HBM is 288 GB
+constexpr size_t kRadBudgetBytes = size_t(16) << 30;  // per-batch radiance planes; HBM is 288 GB (capped by what is free)
 constexpr uint32_t kMaxBatchPaths = 1u << 30;
 constexpr uint32_t kMaxParts = 4;       // parts of the path pool that run on streams of their own
 constexpr uint32_t kDefaultParts = 4;
 constexpr uint32_t kFlagWords = kMaxParts * 32 * 32;  // per part: 32 flag words, one per 128-byte line
 constexpr uint32_t kChunk = 8;  // extend+shade rounds queued between two looks at the alive flag
 constexpr uint32_t kMaxDepthLimit = 4096;  // depth and trail length share one 32-bit word per path
+// Limits of rrt_render_device_noalloc, which works inside the library's static device array (noalloc.hip): with all three
+// at their maximum the path pool takes 5.8 MB and one sample of radiance plus the sums 7.3 MB of the 16 MiB.
+constexpr uint32_t kNoAllocSlots = 16384;
+constexpr uint32_t kNoAllocMaxPixels = 512 * 512;
+constexpr uint32_t kNoAllocMaxDepth = 64;
+
+// The pieces of device memory one render call works in: the path pool, its bookkeeping, the framebuffer planes.
+enum WsPiece { WS_RAYA, WS_RAYB, WS_RAYC, WS_RECENT, WS_RNG, WS_DEPTH, WS_HIT, WS_TRAIL, WS_QUEUE, WS_QCOUNT, WS_WAVE_STATS, WS_CURSORS,
+               WS_FLAGS, WS_STATS_OUT, WS_ACCUM, WS_RAD, WS_PIXEL_MAP, WS_COUNT };
+
+struct RenderPlan {
+    uint32_t npix = 0, batch = 0, slots = 0, n_waves = 0, trail_levels = 1;
+    bool want_map = false;
+    size_t bytes[WS_COUNT] = {};
+    // fills bytes[] from the sizes above; returns the total with every piece rounded up to 256 bytes
+    size_t size_pieces() {
+        const size_t sl = slots;
+        bytes[WS_RAYA] = bytes[WS_RAYB] = bytes[WS_RAYC] = bytes[WS_RECENT] = bytes[WS_RNG] = sl * 16;
+        bytes[WS_DEPTH] = sl * 4; bytes[WS_HIT] = sl * 8; bytes[WS_TRAIL] = sl * 4 * trail_levels; bytes[WS_QUEUE] = sl * 4;
+        bytes[WS_QCOUNT] = (size_t)n_waves * 4; bytes[WS_WAVE_STATS] = (size_t)n_waves * kWaveStatWords * 8;
+        bytes[WS_CURSORS] = (size_t)kCursorShards * kCursorStride * 4; bytes[WS_FLAGS] = kFlagWords * 4; bytes[WS_STATS_OUT] = kWaveStatWords * 8;
+        bytes[WS_ACCUM] = (size_t)npix * 12; bytes[WS_RAD] = (size_t)batch * npix * 16; bytes[WS_PIXEL_MAP] = want_map ? (size_t)npix * 4 : 0;
+        size_t total = 0;
+        for (size_t b : bytes) total += (b + 255) & ~size_t(255);
+        return total;
+    }
+};
 
 }  // namespace
 
@@ -71,10 +99,12 @@ struct rrt_ctx {
     uint32_t n_spheres = 0, n_nodes = 0;
     CameraDev cam{};
     bool has_cam = false;
-    // path state
-    DevBuf rayA, rayB, rayC, recent, rng, depth, hit, trail, queue, qcount, wave_stats, cursors, flags, stats_out;
-    DevBuf accum, rad, pixel_map, tmp_rgb, tmp_acc;
-    uint32_t *h_flags = nullptr;   // pinned
+    // the render workspace (one buffer per piece, grown on demand) and staging for the host-buffer entry points
+    DevBuf ws[WS_COUNT];
+    DevBuf tmp_rgb, tmp_acc;
+    void *scratch = nullptr;       // this device's copy of the library's static workspace (rrt_render_device_noalloc)
+    size_t scratch_bytes = 0;
+    uint32_t *h_flags = nullptr;   // pinned: kFlagWords alive flags, then the path cursors
     uint64_t *h_stats = nullptr;   // pinned
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> kev;   // event pairs around extend launches
@@ -109,7 +139,7 @@ int rrt_create(int device, rrt_ctx **out) {
     c->device = device;
     if (hipGetDeviceProperties(&c->prop, device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || !make_side_streams(c) ||
-        hipHostMalloc(reinterpret_cast<void **>(&c->h_flags), sizeof(uint32_t) * kFlagWords, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **>(&c->h_flags), sizeof(uint32_t) * (kFlagWords + kCursorShards * kCursorStride), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&c->h_stats), sizeof(uint64_t) * kWaveStatWords, hipHostMallocDefault) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
         rrt_destroy(c);
@@ -124,10 +154,10 @@ void rrt_destroy(rrt_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (hipStream_t ss : c->side_stream) if (ss) (void)hipStreamSynchronize(ss);
-    for (DevBuf *b : {&c->nodes, &c->small_nodes, &c->top_nodes, &c->sph, &c->motion, &c->motion_dt, &c->sph_info, &c->prim_att, &c->rayA, &c->rayB, &c->rayC, &c->recent, &c->rng,
-                      &c->depth, &c->hit, &c->trail, &c->queue, &c->qcount, &c->wave_stats, &c->cursors, &c->flags, &c->stats_out,
-                      &c->accum, &c->rad, &c->pixel_map, &c->tmp_rgb, &c->tmp_acc, &c->q_org, &c->q_dir, &c->q_time, &c->q_t, &c->q_obj})
+    for (DevBuf *b : {&c->nodes, &c->small_nodes, &c->top_nodes, &c->sph, &c->motion, &c->motion_dt, &c->sph_info, &c->prim_att,
+                      &c->tmp_rgb, &c->tmp_acc, &c->q_org, &c->q_dir, &c->q_time, &c->q_t, &c->q_obj})
         b->release();
+    for (DevBuf &b : c->ws) b.release();
     for (hipEvent_t ev : c->kev) (void)hipEventDestroy(ev);
     if (c->h_flags) (void)hipHostFree(c->h_flags);
     if (c->h_stats) (void)hipHostFree(c->h_stats);
@@ -148,8 +178,21 @@ int rrt_device_info(rrt_ctx *c, char *name, size_t name_len, int *cus, uint64_t 
     return RRT_OK;
 }
 
+namespace {
+int upload_scene_impl(rrt_ctx *c, const rrt_sphere_soa *sp, const rrt_material_soa *mt, const rrt_bvh_node *nodes, uint32_t n_nodes);
+}
+
 int rrt_upload_scene(rrt_ctx *c, const rrt_sphere_soa *sp, const rrt_material_soa *mt, const rrt_bvh_node *nodes, uint32_t n_nodes) {
     if (!c) return fail(RRT_ERR_INVALID_ARGUMENT, "null context");
+    try {
+        return upload_scene_impl(c, sp, mt, nodes, n_nodes);
+    } catch (const std::exception &e) {  // bad_alloc / system_error of the host-side layout pass
+        return fail(RRT_ERR_OUT_OF_MEMORY, std::string("rrt_upload_scene: ") + e.what());
+    }
+}
+
+namespace {
+int upload_scene_impl(rrt_ctx *c, const rrt_sphere_soa *sp, const rrt_material_soa *mt, const rrt_bvh_node *nodes, uint32_t n_nodes) {
     SceneLayout L;
     std::string err;
     int rc = build_scene_layout(sp, mt, nodes, n_nodes, L, err);
@@ -194,6 +237,7 @@ int rrt_upload_scene(rrt_ctx *c, const rrt_sphere_soa *sp, const rrt_material_so
     c->has_scene = true;
     return RRT_OK;
 }
+}  // namespace
 
 int rrt_set_camera(rrt_ctx *c, const rrt_camera *cam) {
     if (!c || !cam) return fail(RRT_ERR_INVALID_ARGUMENT, "null argument");
@@ -226,7 +270,25 @@ void tile_pixels(uint32_t nx, uint32_t ny, uint32_t rank, uint32_t world, std::v
     }
 }
 
-int render_impl(rrt_ctx *c, const rrt_render_params *pp, void *d_rgb8, void *d_accum, rrt_stats *stats) {
+// What the caller of render_impl supplies besides the context and the parameters.
+struct RenderTarget {
+    void *d_rgb8 = nullptr, *d_accum = nullptr;      // device memory of the caller (nullable)
+    rrt_stats *stats = nullptr;
+    volatile uint64_t *progress = nullptr;           // finished pixels, updated while the call runs (lib.rs:109)
+    void *workspace = nullptr;                       // null: the context's own buffers, grown on demand; else: carve everything
+    size_t workspace_bytes = 0;                      // out of this memory and allocate nothing
+};
+
+// Waits for everything the context has queued, on every stream.  Error paths call it so that no kernel of a failed
+// render is still running on a side stream when the caller's next call reuses the buffers.
+void drain(rrt_ctx *c) {
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (hipStream_t ss : c->side_stream) if (ss) (void)hipStreamSynchronize(ss);
+}
+
+int render_queued(rrt_ctx *c, const rrt_render_params &P, const RenderTarget &T, rrt_stats &st, size_t &kev_used, uint32_t &n_waves_out);
+
+int render_impl(rrt_ctx *c, const rrt_render_params *pp, const RenderTarget &T) {
     if (!c || !pp) return fail(RRT_ERR_INVALID_ARGUMENT, "null argument");
     if (!c->has_scene || !c->has_cam) return fail(RRT_ERR_NOT_READY, "render before rrt_upload_scene / rrt_set_camera");
     const rrt_render_params P = *pp;
@@ -237,141 +299,18 @@ int render_impl(rrt_ctx *c, const rrt_render_params *pp, void *d_rgb8, void *d_a
     const uint32_t rank = P.shard_mode == RRT_SHARD_NONE ? 0u : P.shard_rank;
     if (P.shard_mode > RRT_SHARD_SAMPLE || world == 0 || rank >= world) return fail(RRT_ERR_INVALID_ARGUMENT, "bad shard description");
     HIP_TRY(hipSetDevice(c->device));
-    hipStream_t s = c->stream;
-    const uint32_t npix_img = P.nx * P.ny;
-
-    // ---- which pixels and which samples this call renders ----
-    uint32_t npix = npix_img;
-    const uint32_t *d_map = nullptr;
-    if (P.shard_mode == RRT_SHARD_TILE && world > 1) {
-        std::vector<uint32_t> map;
-        tile_pixels(P.nx, P.ny, rank, world, map);
-        npix = (uint32_t)map.size();
-        HIP_TRY(c->pixel_map.ensure(std::max<size_t>(16, map.size() * 4)));
-        if (npix) HIP_TRY(hipMemcpyAsync(c->pixel_map.p, map.data(), map.size() * 4, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipStreamSynchronize(s));  // `map` dies at the end of this scope
-        d_map = c->pixel_map.as<uint32_t>();
-    }
-    uint32_t k_first = 0, k_step = 1, ns_local = P.ns;
-    if (P.shard_mode == RRT_SHARD_SAMPLE && world > 1) {
-        k_first = rank; k_step = world;
-        ns_local = rank < P.ns ? (P.ns - rank + world - 1) / world : 0;
-    }
-
-    if (d_rgb8) HIP_TRY(hipMemsetAsync(d_rgb8, 0, (size_t)npix_img * 3, s));
-    if (d_accum) HIP_TRY(hipMemsetAsync(d_accum, 0, (size_t)npix_img * 12, s));
+    if (T.progress) *T.progress = 0;
     rrt_stats st{};
-    HIP_TRY(hipEventRecord(c->ev0, s));
-
-    uint32_t n_waves = 0;
     size_t kev_used = 0;
-    const bool count = P.count_work != 0;
-    const uint32_t retire_min = P.reserved[2] ? std::min<uint32_t>(P.reserved[2], 64u) : 32u;  // tuning knob of the extend kernel
-    const uint32_t leaf_min = P.reserved[3] ? std::min<uint32_t>(P.reserved[3], 64u) : 16u;
-    SceneDev sd = c->sd;
-    if (P.reserved[1] & 1u) sd.small_nodes = nullptr;  // walk the HBM copy of the BVH even if the scene fits in LDS
-    // reserved[0] = n: HIP events around every n-th extend launch of each part (n divides the rounds of a chunk, so the
-    // timed launches are an even 1-in-n sample); the counting build times every launch
-    const uint32_t time_stride = count ? 1u : (P.reserved[0] <= kChunk && P.reserved[0] != 0 && kChunk % P.reserved[0] == 0 ? P.reserved[0] : (P.reserved[0] ? 1u : 0u));
-    if (npix > 0 && ns_local > 0) {
-        // ---- batch and slot sizing ----
-        uint32_t batch = P.batch_samples ? P.batch_samples : (uint32_t)std::max<size_t>(1, kRadBudgetBytes / ((size_t)npix * 16));
-        batch = std::min(batch, ns_local);
-        batch = std::min<uint32_t>(batch, std::max<uint32_t>(1, kMaxBatchPaths / npix));
-        const uint32_t rad_plane = batch * npix;
-        uint32_t slots = P.path_slots ? P.path_slots : kDefaultSlots;
-        slots = std::min<uint64_t>(slots, ((uint64_t)rad_plane + kWaveSlots - 1) / kWaveSlots * kWaveSlots);
-        slots = std::max(kWaveSlots, (slots + kWaveSlots - 1) / kWaveSlots * kWaveSlots);
-        n_waves = slots / kWaveSlots;
-        const uint32_t trail_levels = std::max<uint32_t>(1, P.max_depth);
-
-        HIP_TRY(c->rayA.ensure((size_t)slots * 16)); HIP_TRY(c->rayB.ensure((size_t)slots * 16)); HIP_TRY(c->rayC.ensure((size_t)slots * 16)); HIP_TRY(c->recent.ensure((size_t)slots * 16));
-        HIP_TRY(c->rng.ensure((size_t)slots * 16)); HIP_TRY(c->depth.ensure((size_t)slots * 4));
-        HIP_TRY(c->hit.ensure((size_t)slots * 8)); HIP_TRY(c->trail.ensure((size_t)slots * 4 * trail_levels));
-        HIP_TRY(c->queue.ensure((size_t)slots * 4)); HIP_TRY(c->qcount.ensure((size_t)n_waves * 4));
-        HIP_TRY(c->wave_stats.ensure((size_t)n_waves * kWaveStatWords * 8));
-        HIP_TRY(c->cursors.ensure((size_t)kCursorShards * kCursorStride * 4));
-        HIP_TRY(c->flags.ensure(kFlagWords * 4)); HIP_TRY(c->stats_out.ensure(kWaveStatWords * 8));
-        HIP_TRY(c->accum.ensure((size_t)npix * 12)); HIP_TRY(c->rad.ensure((size_t)rad_plane * 16));
-
-        PathState ps{};
-        ps.rayA = c->rayA.as<float4>(); ps.rayB = c->rayB.as<float4>(); ps.rayC = c->rayC.as<float4>(); ps.recent = c->recent.as<uint4>(); ps.rng = c->rng.as<uint4>();
-        ps.depth = c->depth.as<uint32_t>(); ps.hit = c->hit.as<uint2>(); ps.trail = c->trail.as<uint32_t>();
-        ps.queue = c->queue.as<uint32_t>(); ps.qcount = c->qcount.as<uint32_t>(); ps.n_slots = slots; ps.trail_levels = trail_levels;
-        ps.wave_begin = 0; ps.wave_end = n_waves;
-        uint64_t *wstats = c->wave_stats.as<uint64_t>();
-        HIP_TRY(hipMemsetAsync(wstats, 0, (size_t)n_waves * kWaveStatWords * 8, s));
-        uint32_t *flags = c->flags.as<uint32_t>();
-
-        // The path pool is worked on in parts, each with its own stream running extend, shade, extend, ... freely, so
-        // that the extend kernel of one part (VALU-bound) runs beside the shade kernel of another (bound by memory
-        // latency).  RRT_STREAMS=1..4 picks the number of parts.
-        const char *env_streams = std::getenv("RRT_STREAMS");
-        uint32_t n_parts = kDefaultParts;
-        if (env_streams && env_streams[0] >= '1' && env_streams[0] <= '0' + (int)kMaxParts) n_parts = (uint32_t)(env_streams[0] - '0');
-        if (n_waves < 32 * n_parts) n_parts = 1;
-        PathState part[kMaxParts];
-        hipStream_t part_stream[kMaxParts];
-        for (uint32_t h = 0; h < n_parts; h++) {
-            part[h] = ps;
-            part[h].wave_begin = (uint32_t)((uint64_t)n_waves * h / n_parts);
-            part[h].wave_end = (uint32_t)((uint64_t)n_waves * (h + 1) / n_parts);
-            part_stream[h] = h == 0 ? s : c->side_stream[h - 1];
-        }
-
-        for (uint32_t s0 = 0; s0 < ns_local; s0 += batch) {
-            const uint32_t nb = std::min(batch, ns_local - s0);
-            BatchDev bd{};
-            bd.nx = P.nx; bd.ny = P.ny; bd.npix = npix; bd.pixel_map = d_map;
-            bd.div_nx = make_fastdiv(P.nx); bd.div_npix = make_fastdiv(npix);
-            bd.n_paths = nb * npix;
-            bd.k_first = k_first + s0 * k_step; bd.k_step = k_step;
-            bd.seed = P.seed;
-            bd.rad = c->rad.as<float4>();
-            bd.max_depth = P.max_depth;
-            bd.cursors = c->cursors.as<uint32_t>();
-            bd.n_shards = std::min(kCursorShards, n_waves);
-            bd.alive_flag = nullptr;  // raygen's survivors are not looked at
-            HIP_TRY(hipMemsetAsync(bd.cursors, 0, (size_t)kCursorShards * kCursorStride * 4, s));
-            launch_raygen(s, ps, bd, c->cam, wstats);
-            for (;;) {
-                HIP_TRY(hipMemsetAsync(flags, 0, kFlagWords * 4, s));
-                if (n_parts > 1) {
-                    HIP_TRY(hipEventRecord(c->ev_fork, s));
-                    for (uint32_t h = 1; h < n_parts; h++) HIP_TRY(hipStreamWaitEvent(part_stream[h], c->ev_fork, 0));
-                }
-                for (uint32_t it = 0; it < kChunk; it++) {
-                    for (uint32_t h = 0; h < n_parts; h++) {
-                        hipStream_t sp = part_stream[h];
-                        const bool time_kernels = time_stride != 0 && it % time_stride == 0;
-                        if (time_kernels) {
-                            while (c->kev.size() < kev_used + 2) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); c->kev.push_back(ev); }
-                            HIP_TRY(hipEventRecord(c->kev[kev_used], sp));
-                        }
-                        launch_extend(sp, sd, part[h], c->moving, count, retire_min, leaf_min, wstats);
-                        if (time_kernels) { HIP_TRY(hipEventRecord(c->kev[kev_used + 1], sp)); kev_used += 2; }
-                        bd.alive_flag = it + 1 == kChunk ? flags + h * 1024 : nullptr;  // only the chunk's last round reports
-                        launch_shade(sp, sd, part[h], bd, c->cam, c->moving, count, wstats);
-                    }
-                }
-                st.iterations += kChunk;
-                HIP_TRY(hipGetLastError());
-                for (uint32_t h = 1; h < n_parts; h++) { HIP_TRY(hipEventRecord(c->ev_join[h - 1], part_stream[h])); HIP_TRY(hipStreamWaitEvent(s, c->ev_join[h - 1], 0)); }
-                HIP_TRY(hipMemcpyAsync(c->h_flags, flags, kFlagWords * 4, hipMemcpyDeviceToHost, s));
-                HIP_TRY(hipStreamSynchronize(s));
-                uint32_t any = 0;
-                for (uint32_t k = 0; k < kFlagWords; k += 32) any |= c->h_flags[k];
-                if (!any) break;
-            }
-            launch_accumulate(s, c->accum.as<float>(), npix, c->rad.as<float4>(), nb, s0 == 0);
-        }
-        launch_finalize(s, c->accum.as<float>(), npix, d_map, P.ns, static_cast<uint8_t *>(d_rgb8), static_cast<float *>(d_accum));
-        launch_reduce_stats(s, wstats, n_waves, c->stats_out.as<uint64_t>());
-        HIP_TRY(hipMemcpyAsync(c->h_stats, c->stats_out.p, kWaveStatWords * 8, hipMemcpyDeviceToHost, s));
+    uint32_t n_waves = 0;
+    const int rc = render_queued(c, P, T, st, kev_used, n_waves);
+    if (rc != RRT_OK) {
+        const std::string msg = g_err;
+        drain(c);
+        (void)hipGetLastError();
+        g_err = msg;
+        return rc;
     }
-    HIP_TRY(hipEventRecord(c->ev1, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    HIP_TRY(hipGetLastError());
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     st.gpu_ms = ms;
@@ -389,7 +328,193 @@ int render_impl(rrt_ctx *c, const rrt_render_params *pp, void *d_rgb8, void *d_a
     }
     st.extend_ms = ext;
     st.extend_launches = kev_used / 2;
-    if (stats) *stats = st;
+    if (T.stats) *T.stats = st;
+    return RRT_OK;
+}
+
+// Everything of a render call that queues work; returns with all streams idle on success.
+int render_queued(rrt_ctx *c, const rrt_render_params &P, const RenderTarget &T, rrt_stats &st, size_t &kev_used, uint32_t &n_waves_out) {
+    const bool no_alloc = T.workspace != nullptr;
+    const uint32_t world = P.shard_mode == RRT_SHARD_NONE ? 1u : P.shard_world;
+    const uint32_t rank = P.shard_mode == RRT_SHARD_NONE ? 0u : P.shard_rank;
+    hipStream_t s = c->stream;
+    const uint32_t npix_img = P.nx * P.ny;
+    void *const d_rgb8 = T.d_rgb8, *const d_accum = T.d_accum;
+
+    // ---- which pixels and which samples this call renders ----
+    RenderPlan pl;
+    pl.npix = npix_img;
+    std::vector<uint32_t> map;
+    if (P.shard_mode == RRT_SHARD_TILE && world > 1) {
+        if (no_alloc) return fail(RRT_ERR_INVALID_ARGUMENT, "the no-allocation entry point takes RRT_SHARD_NONE or RRT_SHARD_SAMPLE only");
+        tile_pixels(P.nx, P.ny, rank, world, map);
+        pl.npix = (uint32_t)map.size();
+        pl.want_map = true;
+    }
+    const uint32_t npix = pl.npix;
+    uint32_t k_first = 0, k_step = 1, ns_local = P.ns;
+    if (P.shard_mode == RRT_SHARD_SAMPLE && world > 1) {
+        k_first = rank; k_step = world;
+        ns_local = rank < P.ns ? (P.ns - rank + world - 1) / world : 0;
+    }
+
+    if (d_rgb8) HIP_TRY(hipMemsetAsync(d_rgb8, 0, (size_t)npix_img * 3, s));
+    if (d_accum) HIP_TRY(hipMemsetAsync(d_accum, 0, (size_t)npix_img * 12, s));
+    HIP_TRY(hipEventRecord(c->ev0, s));
+
+    const bool count = P.count_work != 0;
+    const uint32_t retire_min = P.reserved[2] ? std::min<uint32_t>(P.reserved[2], 64u) : 32u;  // tuning knob of the extend kernel
+    const uint32_t leaf_min = P.reserved[3] ? std::min<uint32_t>(P.reserved[3], 64u) : 16u;
+    SceneDev sd = c->sd;
+    if (P.reserved[1] & 1u) sd.small_nodes = nullptr;  // walk the HBM copy of the BVH even if the scene fits in LDS
+    // reserved[0] = n: HIP events around every n-th extend launch of each part (n divides the rounds of a chunk, so the
+    // timed launches are an even 1-in-n sample); the counting build times every launch.  Timing creates events on
+    // demand, so the entry point that must not allocate leaves it out.
+    uint32_t time_stride = count ? 1u : (P.reserved[0] <= kChunk && P.reserved[0] != 0 && kChunk % P.reserved[0] == 0 ? P.reserved[0] : (P.reserved[0] ? 1u : 0u));
+    if (no_alloc) time_stride = 0;
+    if (npix > 0 && ns_local > 0) {
+        // ---- batch and slot sizing ----
+        pl.trail_levels = std::max<uint32_t>(1, P.max_depth);
+        uint32_t slots = P.path_slots ? P.path_slots : (no_alloc ? kNoAllocSlots : kDefaultSlots);
+        if (no_alloc) {
+            if (npix > kNoAllocMaxPixels || pl.trail_levels > kNoAllocMaxDepth || slots > kNoAllocSlots)
+                return fail(RRT_ERR_INVALID_ARGUMENT, "the no-allocation entry point takes at most " + std::to_string(kNoAllocMaxPixels) +
+                            " pixels, max_depth " + std::to_string(kNoAllocMaxDepth) + " and " + std::to_string(kNoAllocSlots) + " path slots");
+        }
+        size_t rad_budget = kRadBudgetBytes;
+        if (!no_alloc) {  // leave room for whatever else lives on the device
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) rad_budget = std::min(rad_budget, std::max<size_t>(free_b / 2 + c->ws[WS_RAD].cap, size_t(64) << 20));
+        }
+        uint32_t batch = P.batch_samples ? P.batch_samples : (uint32_t)std::max<size_t>(1, rad_budget / ((size_t)npix * 16));
+        batch = std::min(batch, ns_local);
+        batch = std::min<uint32_t>(batch, std::max<uint32_t>(1, kMaxBatchPaths / npix));
+        slots = std::min<uint64_t>(slots, ((uint64_t)batch * npix + kWaveSlots - 1) / kWaveSlots * kWaveSlots);
+        slots = std::max(kWaveSlots, (slots + kWaveSlots - 1) / kWaveSlots * kWaveSlots);
+        pl.slots = slots;
+        pl.n_waves = slots / kWaveSlots;
+        pl.batch = batch;
+        void *piece[WS_COUNT] = {};
+        if (no_alloc) {
+            // as many samples per batch as the workspace holds beside the path pool
+            pl.batch = 0;
+            const size_t fixed = pl.size_pieces();
+            if (fixed + (((size_t)npix * 16 + 255) & ~size_t(255)) > T.workspace_bytes) return fail(RRT_ERR_INVALID_ARGUMENT, "workspace too small");
+            pl.batch = (uint32_t)std::min<size_t>(batch, (T.workspace_bytes - fixed - 256) / ((size_t)npix * 16));
+            pl.size_pieces();
+            char *at = static_cast<char *>(T.workspace);
+            for (int i = 0; i < WS_COUNT; i++) { piece[i] = at; at += (pl.bytes[i] + 255) & ~size_t(255); }
+        } else {
+            pl.size_pieces();
+            for (int i = 0; i < WS_COUNT; i++) { HIP_TRY(c->ws[i].ensure(std::max<size_t>(16, pl.bytes[i]))); piece[i] = c->ws[i].p; }
+        }
+        batch = pl.batch;
+        const uint32_t n_waves = pl.n_waves;
+        n_waves_out = n_waves;
+        auto at = [&](int i) { return piece[i]; };
+
+        const uint32_t *d_map = nullptr;
+        if (pl.want_map) {
+            HIP_TRY(hipMemcpyAsync(at(WS_PIXEL_MAP), map.data(), map.size() * 4, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipStreamSynchronize(s));  // pageable source
+            d_map = static_cast<const uint32_t *>(at(WS_PIXEL_MAP));
+        }
+
+        PathState ps{};
+        ps.rayA = static_cast<float4 *>(at(WS_RAYA)); ps.rayB = static_cast<float4 *>(at(WS_RAYB)); ps.rayC = static_cast<float4 *>(at(WS_RAYC));
+        ps.recent = static_cast<uint4 *>(at(WS_RECENT)); ps.rng = static_cast<uint4 *>(at(WS_RNG));
+        ps.depth = static_cast<uint32_t *>(at(WS_DEPTH)); ps.hit = static_cast<uint2 *>(at(WS_HIT)); ps.trail = static_cast<uint32_t *>(at(WS_TRAIL));
+        ps.queue = static_cast<uint32_t *>(at(WS_QUEUE)); ps.qcount = static_cast<uint32_t *>(at(WS_QCOUNT)); ps.n_slots = slots; ps.trail_levels = pl.trail_levels;
+        ps.wave_begin = 0; ps.wave_end = n_waves;
+        uint64_t *wstats = static_cast<uint64_t *>(at(WS_WAVE_STATS));
+        HIP_TRY(hipMemsetAsync(wstats, 0, (size_t)n_waves * kWaveStatWords * 8, s));
+        uint32_t *flags = static_cast<uint32_t *>(at(WS_FLAGS));
+        uint32_t *cursors = static_cast<uint32_t *>(at(WS_CURSORS));
+        float *accum = static_cast<float *>(at(WS_ACCUM));
+        float4 *rad = static_cast<float4 *>(at(WS_RAD));
+
+        // The path pool is worked on in parts, each with its own stream running extend, shade, extend, ... freely, so
+        // that the extend kernel of one part (VALU-bound) runs beside the shade kernel of another (bound by memory
+        // latency).  RRT_STREAMS=1..4 picks the number of parts.
+        const char *env_streams = std::getenv("RRT_STREAMS");
+        uint32_t n_parts = kDefaultParts;
+        if (env_streams && env_streams[0] >= '1' && env_streams[0] <= '0' + (int)kMaxParts) n_parts = (uint32_t)(env_streams[0] - '0');
+        if (n_waves < 32 * n_parts) n_parts = 1;
+        PathState part[kMaxParts];
+        hipStream_t part_stream[kMaxParts];
+        for (uint32_t h = 0; h < n_parts; h++) {
+            part[h] = ps;
+            part[h].wave_begin = (uint32_t)((uint64_t)n_waves * h / n_parts);
+            part[h].wave_end = (uint32_t)((uint64_t)n_waves * (h + 1) / n_parts);
+            part_stream[h] = h == 0 ? s : c->side_stream[h - 1];
+        }
+        const uint64_t total_paths = (uint64_t)ns_local * npix;
+        for (uint32_t s0 = 0; s0 < ns_local; s0 += batch) {
+            const uint32_t nb = std::min(batch, ns_local - s0);
+            BatchDev bd{};
+            bd.nx = P.nx; bd.ny = P.ny; bd.npix = npix; bd.pixel_map = d_map;
+            bd.div_nx = make_fastdiv(P.nx); bd.div_npix = make_fastdiv(npix);
+            bd.n_paths = nb * npix;
+            bd.k_first = k_first + s0 * k_step; bd.k_step = k_step;
+            bd.seed = P.seed;
+            bd.rad = rad;
+            bd.max_depth = P.max_depth;
+            bd.cursors = cursors;
+            bd.n_shards = std::min(kCursorShards, n_waves);
+            bd.alive_flag = nullptr;  // raygen's survivors are not looked at
+            HIP_TRY(hipMemsetAsync(bd.cursors, 0, (size_t)kCursorShards * kCursorStride * 4, s));
+            launch_raygen(s, ps, bd, c->cam, wstats);
+            for (;;) {
+                HIP_TRY(hipMemsetAsync(flags, 0, kFlagWords * 4, s));
+                if (n_parts > 1) {
+                    HIP_TRY(hipEventRecord(c->ev_fork, s));
+                    for (uint32_t h = 1; h < n_parts; h++) HIP_TRY(hipStreamWaitEvent(part_stream[h], c->ev_fork, 0));
+                }
+                for (uint32_t it = 0; it < kChunk; it++) {
+                    for (uint32_t h = 0; h < n_parts; h++) {
+                        hipStream_t sp = part_stream[h];
+                        bool time_kernels = time_stride != 0 && it % time_stride == 0;
+                        if (time_kernels) {
+                            while (c->kev.size() < kev_used + 2) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); c->kev.push_back(ev); }
+                            HIP_TRY(hipEventRecord(c->kev[kev_used], sp));
+                        }
+                        launch_extend(sp, sd, part[h], c->moving, count, retire_min, leaf_min, wstats);
+                        if (time_kernels) { HIP_TRY(hipEventRecord(c->kev[kev_used + 1], sp)); kev_used += 2; }
+                        bd.alive_flag = it + 1 == kChunk ? flags + h * 1024 : nullptr;  // only the chunk's last round reports
+                        launch_shade(sp, sd, part[h], bd, c->cam, c->moving, count, wstats);
+                    }
+                }
+                st.iterations += kChunk;
+                HIP_TRY(hipGetLastError());
+                for (uint32_t h = 1; h < n_parts; h++) { HIP_TRY(hipEventRecord(c->ev_join[h - 1], part_stream[h])); HIP_TRY(hipStreamWaitEvent(s, c->ev_join[h - 1], 0)); }
+                HIP_TRY(hipMemcpyAsync(c->h_flags, flags, kFlagWords * 4, hipMemcpyDeviceToHost, s));
+                if (T.progress) HIP_TRY(hipMemcpyAsync(c->h_flags + kFlagWords, cursors, (size_t)kCursorShards * kCursorStride * 4, hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                uint32_t any = 0;
+                for (uint32_t k = 0; k < kFlagWords; k += 32) any |= c->h_flags[k];
+                if (T.progress) {
+                    // Paths handed out so far, less those that may still be in flight, are finished; a pixel counts as
+                    // finished in proportion to its finished samples (the reference bumps its counter per pixel, lib.rs:109)
+                    uint64_t claimed = 0;
+                    for (uint32_t k = 0; k < kCursorShards; k++) claimed += c->h_flags[kFlagWords + k * kCursorStride];
+                    claimed = std::min<uint64_t>(claimed, bd.n_paths);
+                    const uint64_t finished = (uint64_t)s0 * npix + (any ? (claimed > slots ? claimed - slots : 0) : bd.n_paths);
+                    const uint64_t px = finished * npix / total_paths;
+                    if (px > *T.progress) *T.progress = px;
+                }
+                if (!any) break;
+            }
+            launch_accumulate(s, accum, npix, rad, nb, s0 == 0);
+        }
+        // a SAMPLE shard's own RGB8 is the image of its samples alone: divide by their number, not by the whole job's
+        launch_finalize(s, accum, npix, d_map, ns_local, static_cast<uint8_t *>(d_rgb8), static_cast<float *>(d_accum));
+        launch_reduce_stats(s, wstats, n_waves, static_cast<uint64_t *>(at(WS_STATS_OUT)));
+        HIP_TRY(hipMemcpyAsync(c->h_stats, at(WS_STATS_OUT), kWaveStatWords * 8, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipEventRecord(c->ev1, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipGetLastError());
+    if (T.progress) *T.progress = npix;  // every pixel of this call is finished (lib.rs:109)
     return RRT_OK;
 }
 
@@ -400,17 +525,23 @@ extern "C" {
 int rrt_build_bvh(rrt_ctx *c, const rrt_sphere_soa *sp, rrt_bvh_node *out_nodes, uint32_t capacity, uint32_t *n_nodes) {
     if (!c || !sp || !out_nodes || !n_nodes) return fail(RRT_ERR_INVALID_ARGUMENT, "rrt_build_bvh: null argument");
     if (sp->n == 0) return fail(RRT_ERR_BAD_SCENE, "rrt_build_bvh: no objects (Bvh::build of an empty scene yields no nodes)");
-    if (sp->n > RRT_NODE_INDEX_MASK / 2u) return fail(RRT_ERR_BAD_SCENE, "rrt_build_bvh: too many objects");
+    if (sp->n > (kRefIndexMask + 1u) / 2u) return fail(RRT_ERR_BAD_SCENE, "rrt_build_bvh: too many objects");  // 2n-1 nodes must fit rrt_upload_scene
     if (!sp->c0x || !sp->c0y || !sp->c0z || !sp->c1x || !sp->c1y || !sp->c1z || !sp->radius)
         return fail(RRT_ERR_INVALID_ARGUMENT, "rrt_build_bvh: null sphere plane");
     HIP_TRY(hipSetDevice(c->device));
-    std::string err;
-    const int rc = rrt_amd::gpu_build_bvh(c->stream, sp, out_nodes, capacity, n_nodes, err);
-    return rc == RRT_OK ? rc : fail(rc, err);
+    try {
+        std::string err;
+        const int rc = rrt_amd::gpu_build_bvh(c->stream, sp, out_nodes, capacity, n_nodes, err);
+        return rc == RRT_OK ? rc : fail(rc, err);
+    } catch (const std::exception &e) { return fail(RRT_ERR_OUT_OF_MEMORY, std::string("rrt_build_bvh: ") + e.what()); }
 }
 
 int rrt_render_device(rrt_ctx *c, const rrt_render_params *p, void *d_rgb8, void *d_accum, rrt_stats *stats) {
-    return render_impl(c, p, d_rgb8, d_accum, stats);
+    try {
+        RenderTarget T;
+        T.d_rgb8 = d_rgb8; T.d_accum = d_accum; T.stats = stats;
+        return render_impl(c, p, T);
+    } catch (const std::exception &e) { return fail(RRT_ERR_OUT_OF_MEMORY, std::string("rrt_render_device: ") + e.what()); }
 }
 
 int rrt_render(rrt_ctx *c, const rrt_render_params *p, uint8_t *out_rgb8, float *out_accum, rrt_stats *stats, volatile uint64_t *progress) {
@@ -418,35 +549,43 @@ int rrt_render(rrt_ctx *c, const rrt_render_params *p, uint8_t *out_rgb8, float 
     if (!out_rgb8) return fail(RRT_ERR_INVALID_ARGUMENT, "out_rgb8 is null");
     const size_t npix = (size_t)p->nx * p->ny;
     if (npix == 0) return fail(RRT_ERR_INVALID_ARGUMENT, "nx and ny must be positive");
-    HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(c->tmp_rgb.ensure(npix * 3));
-    if (out_accum) HIP_TRY(c->tmp_acc.ensure(npix * 12));
-    int rc = render_impl(c, p, c->tmp_rgb.p, out_accum ? c->tmp_acc.p : nullptr, stats);
-    if (rc != RRT_OK) return rc;
-    HIP_TRY(hipMemcpy(out_rgb8, c->tmp_rgb.p, npix * 3, hipMemcpyDeviceToHost));
-    if (out_accum) HIP_TRY(hipMemcpy(out_accum, c->tmp_acc.p, npix * 12, hipMemcpyDeviceToHost));
-    if (progress) *progress = npix;  // every pixel is finished when the call returns (lib.rs:109)
-    return RRT_OK;
+    try {
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(c->tmp_rgb.ensure(npix * 3));
+        if (out_accum) HIP_TRY(c->tmp_acc.ensure(npix * 12));
+        RenderTarget T;
+        T.d_rgb8 = c->tmp_rgb.p; T.d_accum = out_accum ? c->tmp_acc.p : nullptr; T.stats = stats;
+        T.progress = progress;
+        int rc = render_impl(c, p, T);
+        if (rc != RRT_OK) return rc;
+        HIP_TRY(hipMemcpy(out_rgb8, c->tmp_rgb.p, npix * 3, hipMemcpyDeviceToHost));
+        if (out_accum) HIP_TRY(hipMemcpy(out_accum, c->tmp_acc.p, npix * 12, hipMemcpyDeviceToHost));
+        return RRT_OK;
+    } catch (const std::exception &e) { return fail(RRT_ERR_OUT_OF_MEMORY, std::string("rrt_render: ") + e.what()); }
 }
 
 int rrt_validate_scene(const rrt_sphere_soa *sp, const rrt_material_soa *mt, const rrt_bvh_node *nodes, uint32_t n_nodes) {
-    SceneLayout L;
-    std::string err;
-    int rc = build_scene_layout(sp, mt, nodes, n_nodes, L, err);
-    if (rc != RRT_OK) return fail(rc, err);
-    return RRT_OK;
+    try {
+        SceneLayout L;
+        std::string err;
+        int rc = build_scene_layout(sp, mt, nodes, n_nodes, L, err);
+        if (rc != RRT_OK) return fail(rc, err);
+        return RRT_OK;
+    } catch (const std::exception &e) { return fail(RRT_ERR_OUT_OF_MEMORY, std::string("rrt_validate_scene: ") + e.what()); }
 }
 
 int rrt_debug_layout(const rrt_sphere_soa *sp, const rrt_material_soa *mt, const rrt_bvh_node *nodes, uint32_t n_nodes, uint32_t *words16,
                      uint32_t *root_ref, uint32_t *scene_flags) {
-    SceneLayout L;
-    std::string err;
-    int rc = build_scene_layout(sp, mt, nodes, n_nodes, L, err);
-    if (rc != RRT_OK) return fail(rc, err);
-    if (words16) std::memcpy(words16, L.nodes.data(), L.nodes.size() * 4);
-    if (root_ref) *root_ref = L.root_ref;
-    if (scene_flags) *scene_flags = L.flags;
-    return RRT_OK;
+    try {
+        SceneLayout L;
+        std::string err;
+        int rc = build_scene_layout(sp, mt, nodes, n_nodes, L, err);
+        if (rc != RRT_OK) return fail(rc, err);
+        if (words16) std::memcpy(words16, L.nodes.data(), L.nodes.size() * 4);
+        if (root_ref) *root_ref = L.root_ref;
+        if (scene_flags) *scene_flags = L.flags;
+        return RRT_OK;
+    } catch (const std::exception &e) { return fail(RRT_ERR_OUT_OF_MEMORY, std::string("rrt_debug_layout: ") + e.what()); }
 }
 
 uint32_t rrt_shard_pixels(uint32_t nx, uint32_t ny, uint32_t shard_mode, uint32_t rank, uint32_t world, uint32_t *out_idx) {

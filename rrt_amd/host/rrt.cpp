@@ -3,6 +3,9 @@
 // contracts a*b+c, and ultraviolet's explicit mul_add calls are std::fmaf here.
 #include "rrt.hpp"
 
+#include <chrono>
+#include <thread>
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -372,10 +375,26 @@ std::vector<uint8_t> tracescene(size_t nx, size_t ny, size_t ns, const Scene &sc
     p.max_depth = 50;  // lib.rs:58
     p.seed = pool.stream_seed();
     std::vector<uint8_t> pixels(ny * nx * 3, 0);  // lib.rs:82-83
+    // lib.rs:109 bumps `pdc` as pixels finish and main.rs:78-94 polls it from another thread.  The library raises `done`
+    // while it renders; a helper thread forwards the increments to `pdc` so that a poller of `pdc` sees them.
     volatile uint64_t done = 0;
-    if (rrt_render(pool.ctx(), &p, pixels.data(), nullptr, nullptr, &done) != RRT_OK)
-        throw std::runtime_error(std::string("tracescene: ") + rrt_last_error());
-    pdc.fetch_add(static_cast<size_t>(done), std::memory_order_relaxed);  // lib.rs:109
+    uint64_t forwarded = 0;
+    std::atomic<bool> finished{false};
+    auto forward = [&] {
+        const uint64_t now = done;
+        if (now > forwarded) { pdc.fetch_add(static_cast<size_t>(now - forwarded), std::memory_order_relaxed); forwarded = now; }
+    };
+    std::thread relay([&] {
+        while (!finished.load(std::memory_order_acquire)) {
+            forward();
+            std::this_thread::sleep_for(std::chrono::milliseconds(20));
+        }
+    });
+    const int rc = rrt_render(pool.ctx(), &p, pixels.data(), nullptr, nullptr, &done);
+    finished.store(true, std::memory_order_release);
+    relay.join();
+    if (rc != RRT_OK) throw std::runtime_error(std::string("tracescene: ") + rrt_last_error());
+    forward();  // the rest, up to nx*ny
     return pixels;
 }
 

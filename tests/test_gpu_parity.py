@@ -268,6 +268,32 @@ def test_tracescene_mirror(gpu_ctx):
     assert np.array_equal(px, rgb_o)
 
 
+def test_progress_counter_rises_while_rendering(gpu_ctx):
+    """`progress` plays the part of `pdc` (lib.rs:81,109; polled by main.rs:78-94): zero at the start, raised while the call
+    runs, nx*ny at the end.  ctypes releases the GIL for the call, so this thread can poll the word."""
+    import ctypes as C
+    import threading
+    import time
+    nx, ny, ns = 1200, 800, 160
+    hs = rrt_amd.HostScene(rrt_amd.SCENE_CHAP12, nx, ny, seed=0)
+    gpu_ctx.upload_host_scene(hs)
+    p = rrt_amd.Context.params(nx, ny, ns, seed=1, batch_samples=8)
+    rgb = np.zeros((ny, nx, 3), np.uint8)
+    done = C.c_uint64(12345)
+    rc = []
+    t = threading.Thread(target=lambda: rc.append(rrt_amd.lib().rrt_render(gpu_ctx._h, C.byref(p), rgb.ctypes.data, None, None, C.byref(done))))
+    t.start()
+    seen = []
+    while t.is_alive():
+        seen.append(done.value)
+        time.sleep(0.0005)
+    t.join()
+    assert rc == [0] and done.value == nx * ny
+    seen = [v for v in seen if v != 12345]
+    assert all(a <= b for a, b in zip(seen, seen[1:])), "the counter never goes back"
+    assert len({v for v in seen if 0 < v < nx * ny}) >= 3, f"no intermediate values seen: {sorted(set(seen))[:10]}"
+
+
 def test_errors(gpu_ctx):
     fresh = rrt_amd.Context(0)
     with pytest.raises(rrt_amd.RrtError, match="before"):
