@@ -9,7 +9,7 @@ CXXFLAGS:= -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wextra -Wno-unused-pa
 
 LIB     := rrt_amd/librrt_amd.so
 OBJDIR  := build
-OBJS    := $(OBJDIR)/kernels.o $(OBJDIR)/bvh_gpu.o $(OBJDIR)/capi.o $(OBJDIR)/scene_layout.o $(OBJDIR)/rrt.o $(OBJDIR)/host_capi.o
+OBJS    := $(OBJDIR)/kernels.o $(OBJDIR)/noalloc.o $(OBJDIR)/bvh_gpu.o $(OBJDIR)/capi.o $(OBJDIR)/scene_layout.o $(OBJDIR)/rrt.o $(OBJDIR)/host_capi.o
 
 CLI     := rrt_amd/rrt
 
@@ -19,6 +19,9 @@ $(OBJDIR):
 	mkdir -p $(OBJDIR)
 
 $(OBJDIR)/kernels.o: rrt_amd/csrc/kernels.hip rrt_amd/csrc/kernels.h rrt_amd/csrc/scene_layout.h include/rrt_amd.h | $(OBJDIR)
+	$(HIPCC) $(CXXFLAGS) $(DEVFLAGS) -c $< -o $@
+
+$(OBJDIR)/noalloc.o: rrt_amd/csrc/noalloc.hip include/rrt_amd.h | $(OBJDIR)
 	$(HIPCC) $(CXXFLAGS) $(DEVFLAGS) -c $< -o $@
 
 $(OBJDIR)/bvh_gpu.o: rrt_amd/csrc/bvh_gpu.hip include/rrt_amd.h | $(OBJDIR)

@@ -171,6 +171,19 @@ RRT_API int rrt_render(rrt_ctx *ctx, const rrt_render_params *params, uint8_t *o
 RRT_API int rrt_render_device(rrt_ctx *ctx, const rrt_render_params *params, void *d_rgb8, void *d_accum,
                               rrt_stats *stats);
 
+/* rrt_render_device for callers that cannot allocate device memory: code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.  The path pool,
+ * queues, counters, radiance planes and per-pixel sums live in a static array of
+ * RRT_NOALLOC_WORKSPACE_BYTES that is part of the library's code object (every GPU the library runs on
+ * holds it until the process ends); the call makes no hipMalloc / hipFree and creates no events.
+ * Limits, rejected with RRT_ERR_INVALID_ARGUMENT: nx*ny <= 512*512, max_depth <= 64, path_slots <= 16384
+ * (0 = 16384), shard_mode NONE or SAMPLE, no kernel timing (reserved[0] is ignored).  Same image, bit for
+ * bit, as rrt_render_device.  All calls on one GPU share that GPU's array: calls that overlap on one GPU
+ * (two contexts, two threads) race; calls one after another do not, each clears what it needs. */
+#define RRT_NOALLOC_WORKSPACE_BYTES (16u << 20)
+RRT_API int rrt_render_device_noalloc(rrt_ctx *ctx, const rrt_render_params *params, void *d_rgb8, void *d_accum,
+                                      rrt_stats *stats);
+
 /* lib.rs:105-108 on device buffers: rgb8 = saturate_u8(sqrt(accum / ns) * 255.99).  Used after
  * accumulators of SAMPLE shards have been summed across GPUs. */
 RRT_API int rrt_finalize(rrt_ctx *ctx, const void *d_accum, uint32_t n_pixels, uint32_t ns, void *d_rgb8);

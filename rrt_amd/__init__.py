@@ -101,6 +101,7 @@ def lib() -> C.CDLL:
     L.rrt_set_camera.argtypes = [vp, C.POINTER(Camera)]
     L.rrt_render.argtypes = [vp, C.POINTER(RenderParams), vp, vp, C.POINTER(Stats), vp]
     L.rrt_render_device.argtypes = [vp, C.POINTER(RenderParams), vp, vp, C.POINTER(Stats)]
+    L.rrt_render_device_noalloc.argtypes = [vp, C.POINTER(RenderParams), vp, vp, C.POINTER(Stats)]
     L.rrt_finalize.argtypes = [vp, vp, u32, u32, vp]
     L.rrt_intersect.argtypes = [vp, u32, vp, vp, vp, f32, f32, vp, vp]
     L.rrt_validate_scene.argtypes = [C.POINTER(SphereSoa), C.POINTER(MaterialSoa), vp, u32]
@@ -299,6 +300,12 @@ class Context:
         """rrt_render_device into caller-owned device pointers (0 = skip that output)."""
         st = Stats()
         _check(lib().rrt_render_device(self._h, C.byref(p), d_rgb8 or None, d_accum or None, C.byref(st)), "rrt_render_device")
+        return st.as_dict()
+
+    def render_device_noalloc(self, p: RenderParams, d_rgb8: int, d_accum: int) -> dict:
+        """rrt_render_device_noalloc: the same render inside the library's static workspace, no device allocation."""
+        st = Stats()
+        _check(lib().rrt_render_device_noalloc(self._h, C.byref(p), d_rgb8 or None, d_accum or None, C.byref(st)), "rrt_render_device_noalloc")
         return st.as_dict()
 
     def finalize(self, d_accum: int, n_pixels: int, ns: int, d_rgb8: int) -> None:

@@ -18,6 +18,12 @@ using namespace rrt_amd;
 
 namespace rrt_amd {
 int gpu_build_bvh(hipStream_t st, const rrt_sphere_soa *sp, rrt_bvh_node *out_nodes, uint32_t capacity, uint32_t *n_nodes, std::string &err);
+// noalloc.hip: address and size of the current device's copy of the library's static workspace
+int static_workspace(int device, void **ptr, size_t *bytes, std::string &err);
+// for noalloc.hip: a render call that takes all its device memory from `workspace`
+int render_in_workspace(rrt_ctx *ctx, const rrt_render_params *params, void *d_rgb8, void *d_accum, rrt_stats *stats, void *workspace, size_t workspace_bytes);
+int context_device(const rrt_ctx *ctx);
+int set_error(int code, const std::string &msg);
 }
 
 namespace {
@@ -144,6 +150,11 @@ int rrt_create(int device, rrt_ctx **out) {
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
         rrt_destroy(c);
         return fail(RRT_ERR_HIP, "rrt_create: device set-up failed");
+    }
+    std::string err;
+    if (rrt_amd::static_workspace(device, &c->scratch, &c->scratch_bytes, err) != RRT_OK) {
+        rrt_destroy(c);
+        return fail(RRT_ERR_HIP, "rrt_create: " + err);
     }
     *out = c;
     return RRT_OK;
@@ -633,3 +644,16 @@ int rrt_intersect(rrt_ctx *c, uint32_t n, const float *org, const float *dir, co
 }
 
 }  // extern "C"
+
+namespace rrt_amd {
+
+int render_in_workspace(rrt_ctx *ctx, const rrt_render_params *params, void *d_rgb8, void *d_accum, rrt_stats *stats, void *workspace, size_t workspace_bytes) {
+    RenderTarget T;
+    T.d_rgb8 = d_rgb8; T.d_accum = d_accum; T.stats = stats;
+    T.workspace = workspace; T.workspace_bytes = workspace_bytes;
+    return render_impl(ctx, params, T);
+}
+int context_device(const rrt_ctx *ctx) { return ctx ? ctx->device : -1; }
+int set_error(int code, const std::string &msg) { return fail(code, msg); }
+
+}  // namespace rrt_amd
