@@ -79,6 +79,7 @@ def lib() -> C.CDLL:
     L.orc_render.argtypes = [vp, u32, u32, u32, i32, i32, u64, vp, i32, i32, u32, u32, vp, vp, vp, vp]
     L.orc_render.restype = i32
     L.orc_render_pixels.argtypes = [vp, u32, u32, u32, u64, i32, i32, u32, vp, vp, vp, vp]
+    L.orc_render_pixels_shard.argtypes = [vp, u32, u32, u32, u64, i32, i32, u32, u32, u32, vp, vp, vp, vp]
     L.orc_trace_path.argtypes = [vp, u32, u32, u64, u32, u32, i32, i32, vp, vp]
     _lib = L
     return L
@@ -206,14 +207,19 @@ class OracleScene:
             return rgb, acc, d, ps
         return rgb, acc, d
 
-    def render_pixels(self, nx, ny, ns, seed, idx, max_depth=50, pow5_mode=0):
-        """Per-sample-mode sums and RGB8 of chosen pixels: (acc [n,3] f32, rgb [n,3] u8, rays)."""
+    def render_pixels(self, nx, ny, ns, seed, idx, max_depth=50, pow5_mode=0, k_begin=0, k_step=1):
+        """Per-sample-mode sums and RGB8 of chosen pixels: (acc [n,3] f32, rgb [n,3] u8, rays).  With k_step > 1: the sample
+        shard k = k_begin, k_begin + k_step, ... < ns alone."""
         idx = np.ascontiguousarray(idx, np.uint32)
         acc = np.zeros((idx.shape[0], 3), np.float32)
         rgb = np.zeros((idx.shape[0], 3), np.uint8)
         rays = C.c_uint64(0)
-        lib().orc_render_pixels(self._h, nx, ny, ns, seed, max_depth, pow5_mode, idx.shape[0], idx.ctypes.data, acc.ctypes.data,
-                                rgb.ctypes.data, C.byref(rays))
+        if k_begin == 0 and k_step == 1:
+            lib().orc_render_pixels(self._h, nx, ny, ns, seed, max_depth, pow5_mode, idx.shape[0], idx.ctypes.data, acc.ctypes.data,
+                                    rgb.ctypes.data, C.byref(rays))
+        else:
+            lib().orc_render_pixels_shard(self._h, nx, ny, ns, seed, max_depth, pow5_mode, k_begin, k_step, idx.shape[0], idx.ctypes.data,
+                                          acc.ctypes.data, rgb.ctypes.data, C.byref(rays))
         return acc, rgb, rays.value
 
     def trace_path(self, nx, ny, seed, idx, k, max_depth=50, pow5_mode=0):

@@ -988,6 +988,27 @@ ORC_API void orc_render_pixels(const orc_scene *s, uint32_t nx, uint32_t ny, uin
     if (rays) *rays = C.rays;
 }
 
+/* The same for one sample shard: samples k = k_begin, k_begin + k_step, ... < ns of the chosen pixels, added in that
+ * order (what a rank of a sample-sharded render accumulates); rgb is quantised with the shard's own sample count. */
+ORC_API void orc_render_pixels_shard(const orc_scene *s, uint32_t nx, uint32_t ny, uint32_t ns, uint64_t seed, int max_depth,
+                                     int pow5_mode, uint32_t k_begin, uint32_t k_step, uint32_t n, const uint32_t *idx, float *acc,
+                                     uint8_t *rgb, uint64_t *rays) {
+    opts_t O = {max_depth, pow5_mode};
+    ctrs_t C; memset(&C, 0, sizeof C);
+    if (k_step == 0) k_step = 1;
+    for (uint32_t i = 0; i < n; i++) {
+        v4 c = v4_splat(0.0f);
+        uint32_t n_local = 0;
+        for (uint32_t k = k_begin; k < ns; k += k_step) {
+            xrng g; rng_seed_from_u64(&g, sample_stream_seed(seed, idx[i], k));
+            c = v4_add(c, pixel_sample(&s->sc, &s->cam, nx, ny, idx[i], &g, &C, &O));
+            n_local++;
+        }
+        pixel_finish(c, n_local ? n_local : 1, rgb + (size_t)i * 3, acc + (size_t)i * 3);
+    }
+    if (rays) *rays = C.rays;
+}
+
 /* One path, for debugging and fine-grained parity: radiance of (pixel idx, sample k) in per-sample mode. */
 ORC_API void orc_trace_path(const orc_scene *s, uint32_t nx, uint32_t ny, uint64_t seed, uint32_t idx, uint32_t k,
                             int max_depth, int pow5_mode, float out_rgb[3], uint64_t *rays) {

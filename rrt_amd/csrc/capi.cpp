@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -437,6 +438,7 @@ int render_queued(rrt_ctx *c, const rrt_render_params &P, const RenderTarget &T,
         ps.depth = static_cast<uint32_t *>(at(WS_DEPTH)); ps.hit = static_cast<uint2 *>(at(WS_HIT)); ps.trail = static_cast<uint32_t *>(at(WS_TRAIL));
         ps.queue = static_cast<uint32_t *>(at(WS_QUEUE)); ps.qcount = static_cast<uint32_t *>(at(WS_QCOUNT)); ps.n_slots = slots; ps.trail_levels = pl.trail_levels;
         ps.wave_begin = 0; ps.wave_end = n_waves;
+        ps.t_min = 0.001f; ps.t_max = std::numeric_limits<float>::max();  // lib.rs:57
         uint64_t *wstats = static_cast<uint64_t *>(at(WS_WAVE_STATS));
         HIP_TRY(hipMemsetAsync(wstats, 0, (size_t)n_waves * kWaveStatWords * 8, s));
         uint32_t *flags = static_cast<uint32_t *>(at(WS_FLAGS));
@@ -634,8 +636,20 @@ int rrt_intersect(rrt_ctx *c, uint32_t n, const float *org, const float *dir, co
     HIP_TRY(hipMemcpyAsync(c->q_org.p, org, (size_t)n * 12, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(c->q_dir.p, dir, (size_t)n * 12, hipMemcpyHostToDevice, s));
     if (time) HIP_TRY(hipMemcpyAsync(c->q_time.p, time, (size_t)n * 4, hipMemcpyHostToDevice, s));
-    launch_intersect(s, c->sd, c->moving, n, c->q_org.as<float>(), c->q_dir.as<float>(), time ? c->q_time.as<float>() : nullptr, t_min,
-                     t_max, c->q_t.as<float>(), c->q_obj.as<uint32_t>());
+    // the rays take the first n slots of the path pool, and the render loop's extend kernel walks them
+    RenderPlan pl;
+    pl.slots = (n + kWaveSlots - 1) / kWaveSlots * kWaveSlots;
+    pl.n_waves = pl.slots / kWaveSlots;
+    pl.size_pieces();
+    for (int i : {WS_RAYA, WS_RAYB, WS_RAYC, WS_HIT, WS_QUEUE, WS_QCOUNT, WS_WAVE_STATS}) HIP_TRY(c->ws[i].ensure(std::max<size_t>(16, pl.bytes[i])));
+    PathState ps{};
+    ps.rayA = c->ws[WS_RAYA].as<float4>(); ps.rayB = c->ws[WS_RAYB].as<float4>(); ps.rayC = c->ws[WS_RAYC].as<float4>();
+    ps.hit = c->ws[WS_HIT].as<uint2>(); ps.queue = c->ws[WS_QUEUE].as<uint32_t>(); ps.qcount = c->ws[WS_QCOUNT].as<uint32_t>();
+    ps.n_slots = pl.slots; ps.trail_levels = 1; ps.wave_begin = 0; ps.wave_end = pl.n_waves;
+    ps.t_min = t_min; ps.t_max = t_max;
+    launch_intersect_setup(s, ps, n, c->q_org.as<float>(), c->q_dir.as<float>(), time ? c->q_time.as<float>() : nullptr);
+    launch_extend(s, c->sd, ps, c->moving, false, 32u, 16u, c->ws[WS_WAVE_STATS].as<uint64_t>());
+    launch_intersect_gather(s, ps, n, c->q_t.as<float>(), c->q_obj.as<uint32_t>());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_t, c->q_t.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(out_obj, c->q_obj.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));

@@ -58,6 +58,7 @@ struct PathState {
     uint32_t n_slots;  // multiple of kWaveSlots
     uint32_t trail_levels;  // levels per path in `trail` (the depth limit)
     uint32_t wave_begin, wave_end;  // the waves (slot stretches) one launch works on
+    float t_min, t_max;             // the interval Bvh::hit searches: 0.001 and f32::MAX for a render (lib.rs:57)
 };
 
 // Division of a 32-bit number by an invariant divisor with one multiply-high (Granlund & Montgomery): for every n,
@@ -101,8 +102,10 @@ void launch_finalize(hipStream_t s, const float *accum, uint32_t npix, const uin
                      float *accum_out);
 // rgb8 from interleaved float sums (lib.rs:105-108)
 void launch_finalize_interleaved(hipStream_t s, const float *accum_rgb, uint32_t n_pixels, uint32_t ns, uint8_t *rgb8);
-void launch_intersect(hipStream_t s, const SceneDev &S, bool moving, uint32_t n, const float *org, const float *dir,
-                      const float *time, float t_min, float t_max, float *out_t, uint32_t *out_obj);
+// Bvh::hit alone on caller rays: fills the first n slots of the path pool (ray planes, identity live lists, list lengths) /
+// reads their hit records back.  The walk itself is launch_extend, the kernel a render runs.
+void launch_intersect_setup(hipStream_t s, const PathState &P, uint32_t n, const float *org, const float *dir, const float *time);
+void launch_intersect_gather(hipStream_t s, const PathState &P, uint32_t n, float *out_t, uint32_t *out_obj);
 void launch_reduce_stats(hipStream_t s, const uint64_t *wave_stats, uint32_t n_waves, uint64_t *out16);
 
 }  // namespace rrt_amd

@@ -165,14 +165,6 @@ DEV void ray_load(RayCtx &r, float4 A, float4 B, float4 C, float tmin, float tma
     ray_finish(r, tmin, tmax, S, uniform_times);
 }
 
-DEV void ray_setup(RayCtx &r, float4 A, float4 B, float tmin, float tmax, const SceneDev &S, bool uniform_times) {
-    r.d = mk(B.x, B.y, B.z);
-    r.ox = f32x2{A.x, 1.0f / r.d.x}; r.oy = f32x2{A.y, 1.0f / r.d.y}; r.oz = f32x2{A.z, 1.0f / r.d.z};  // types.rs:21-23
-    r.time = A.w;
-    r.a = dot3(r.d, r.d);
-    ray_finish(r, tmin, tmax, S, uniform_times);
-}
-
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef const u32x4 *HbmNodePtr;
 typedef const __attribute__((address_space(3))) u32x4 *LdsNodePtr;  // spelled out so that the loads are ds_read, not flat_load
@@ -414,7 +406,7 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
             if (take) {
                 slot = n_slot;
                 const float4 nA = P.rayA[n_slot], nB = P.rayB[n_slot], nC = P.rayC[n_slot];
-                ray_load(r, nA, nB, nC, 0.001f, __FLT_MAX__, S, uniform_times);  // lib.rs:57
+                ray_load(r, nA, nB, nC, P.t_min, P.t_max, S, uniform_times);  // lib.rs:57
                 st.prepare(r);
                 cur = st.root();
                 has = true;
@@ -1068,22 +1060,25 @@ __global__ void k_finalize_interleaved(const float *accum_rgb, uint32_t n_values
     rgb8[i] = quantise(accum_rgb[i], (float)ns);
 }
 
-template <bool MOVING>
-__global__ void k_intersect(SceneDev S, uint32_t n, const float *org, const float *dir, const float *time, float t_min, float t_max,
-                            float *out_t, uint32_t *out_obj) {
+// Bvh::hit (acceleration.rs:221-272) alone, for caller-supplied rays: ray i takes path slot i, every wave's live list is
+// the identity over its slots (the last one shorter), and the extend kernel of the render loop does the walk.
+__global__ void k_intersect_setup(PathState P, uint32_t n, const float *org, const float *dir, const float *time) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const HbmStore<MOVING> st(S);
-    RayCtx r;
-    ray_setup(r, make_float4(org[i * 3u], org[i * 3u + 1u], org[i * 3u + 2u], time ? time[i] : 0.0f),
-              make_float4(dir[i * 3u], dir[i * 3u + 1u], dir[i * 3u + 2u], 0.0f), t_min, t_max, S, st.uniform_times());
-    uint32_t cur = st.root();
-    while (cur != HbmStore<MOVING>::kEnd) {
-        while (cur < HbmStore<MOVING>::kEnd) cur = visit_inner(st, cur, r);
-        if (cur != HbmStore<MOVING>::kEnd) cur = visit_leaf(st, cur, r);
-    }
-    out_t[i] = r.tmax;
-    out_obj[i] = r.best == kPrimNone ? kPrimNone : (r.best & kLeafPrimMask);
+    const V3 d = mk(dir[i * 3u], dir[i * 3u + 1u], dir[i * 3u + 2u]);
+    P.rayA[i] = make_float4(org[i * 3u], org[i * 3u + 1u], org[i * 3u + 2u], time ? time[i] : 0.0f);
+    P.rayB[i] = make_float4(d.x, d.y, d.z, 0.0f);
+    P.rayC[i] = ray_constants(d);
+    P.queue[i] = i;
+    if ((i & (kWaveSlots - 1u)) == 0u) P.qcount[i / kWaveSlots] = min(kWaveSlots, n - i);
+}
+
+__global__ void k_intersect_gather(PathState P, uint32_t n, float *out_t, uint32_t *out_obj) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint2 h = P.hit[i];
+    out_t[i] = u2f(h.x);
+    out_obj[i] = h.y == kPrimNone ? kPrimNone : (h.y & kLeafPrimMask);
 }
 
 __global__ void k_reduce_stats(const uint64_t *wave_stats, uint32_t n_waves, uint64_t *out16) {
@@ -1189,11 +1184,12 @@ void launch_finalize_interleaved(hipStream_t s, const float *accum_rgb, uint32_t
     hipLaunchKernelGGL(k_finalize_interleaved, dim3((n + 255u) / 256u), dim3(256), 0, s, accum_rgb, n, ns, rgb8);
 }
 
-void launch_intersect(hipStream_t s, const SceneDev &S, bool moving, uint32_t n, const float *org, const float *dir,
-                      const float *time, float t_min, float t_max, float *out_t, uint32_t *out_obj) {
-    const dim3 g((n + 255u) / 256u), b(256);
-    if (moving) hipLaunchKernelGGL((k_intersect<true>), g, b, 0, s, S, n, org, dir, time, t_min, t_max, out_t, out_obj);
-    else hipLaunchKernelGGL((k_intersect<false>), g, b, 0, s, S, n, org, dir, time, t_min, t_max, out_t, out_obj);
+void launch_intersect_setup(hipStream_t s, const PathState &P, uint32_t n, const float *org, const float *dir, const float *time) {
+    hipLaunchKernelGGL(k_intersect_setup, dim3((n + 255u) / 256u), dim3(256), 0, s, P, n, org, dir, time);
+}
+
+void launch_intersect_gather(hipStream_t s, const PathState &P, uint32_t n, float *out_t, uint32_t *out_obj) {
+    hipLaunchKernelGGL(k_intersect_gather, dim3((n + 255u) / 256u), dim3(256), 0, s, P, n, out_t, out_obj);
 }
 
 void launch_reduce_stats(hipStream_t s, const uint64_t *wave_stats, uint32_t n_waves, uint64_t *out16) {

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Writes tests/golden/fullsize.json: digests of whole oracle renders at the sizes of the headline configurations
-(chap12 1200x800x500 and book2chap2 1200x800x100, scene seed 0, render seed 0, depth 50), per-sample mode.
+(chap12 1200x800x500 and book2chap2 1200x800x500, scene seed 0, render seed 0, depth 50), per-sample mode.
 
 A full-size image is too big for a fixture, so what is kept is the SHA-256 of the RGB8 bytes and of the f32 sums, the
 CRC-32 of every row of f32 sums (to point at the rows that differ when a digest does), and the work counters.  Takes
@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from oracle import CTR_NAMES, MODE_PER_SAMPLE, OracleScene  # noqa: E402
 
-CASES = [("chap12_1200x800x500", 1, 1200, 800, 500), ("book2chap2_1200x800x100", 2, 1200, 800, 100)]
+CASES = [("chap12_1200x800x500", 1, 1200, 800, 500), ("book2chap2_1200x800x500", 2, 1200, 800, 500)]
 
 
 def digest(rgb, acc):

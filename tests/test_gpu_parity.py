@@ -338,7 +338,85 @@ def test_full_chap12_1200x800x500_spot(gpu_ctx):
 
 
 def test_full_book2chap2_1200x800_spot(gpu_ctx):
-    spot_check(gpu_ctx, SCENES["book2chap2"], 1200, 800, 100, seed=0, n_pixels=64)
+    spot_check(gpu_ctx, SCENES["book2chap2"], 1200, 800, 500, seed=0, n_pixels=64)
+
+
+# ---- the target configuration: chap12 at 3840x2160, 1024 samples per pixel, sharded by tile and by sample
+CFG4 = (3840, 2160, 1024)
+
+
+@pytest.fixture(scope="module")
+def cfg4_unsharded(gpu_ctx):
+    nx, ny, ns = CFG4
+    osc = OracleScene.build(SCENES["chap12"], nx, ny, seed=0)
+    upload_from_oracle(gpu_ctx, osc)
+    rgb, acc, st = gpu_ctx.render(rrt_amd.Context.params(nx, ny, ns, seed=0))
+    idx = np.random.default_rng(4).choice(nx * ny, 96, replace=False).astype(np.uint32)
+    return osc, rgb, acc, st, idx
+
+
+def test_cfg4_4k_1024spp_unsharded_spot(gpu_ctx, cfg4_unsharded):
+    nx, ny, ns = CFG4
+    osc, rgb, acc, st, idx = cfg4_unsharded
+    acc_o, rgb_o, rays_o = osc.render_pixels(nx, ny, ns, 0, idx)
+    assert np.array_equal(bits(acc.reshape(-1, 3)[idx]), bits(acc_o))
+    assert np.array_equal(rgb.reshape(-1, 3)[idx], rgb_o)
+    assert st["paths"] == nx * ny * ns
+    assert rgb.mean() > 20
+
+
+def test_cfg4_4k_1024spp_as_8_tile_shards(gpu_ctx, cfg4_unsharded):
+    """Eight TILE shards rendered one after the other on this device and combined the way the ranks of a node combine them
+    (zero-filled full-size buffers added up): the composite is the unsharded image bit for bit, and equals the oracle."""
+    nx, ny, ns = CFG4
+    osc, rgb_full, acc_full, st_full, idx = cfg4_unsharded
+    upload_from_oracle(gpu_ctx, osc)
+    world = 8
+    rgb = np.zeros_like(rgb_full)
+    acc = np.zeros_like(acc_full)
+    rays = paths = 0
+    for rank in range(world):
+        r, a, st = gpu_ctx.render(rrt_amd.Context.params(nx, ny, ns, seed=0, shard_mode=rrt_amd.SHARD_TILE, rank=rank, world=world))
+        assert st["progress"] == rrt_amd.shard_pixels(nx, ny, rrt_amd.SHARD_TILE, rank, world).size
+        rgb += r
+        acc += a
+        rays += st["rays"]
+        paths += st["paths"]
+    assert paths == nx * ny * ns and rays == st_full["rays"]
+    assert np.array_equal(rgb, rgb_full)
+    assert np.array_equal(bits(acc), bits(acc_full))
+    acc_o, rgb_o, _ = osc.render_pixels(nx, ny, ns, 0, idx)
+    assert np.array_equal(bits(acc.reshape(-1, 3)[idx]), bits(acc_o)) and np.array_equal(rgb.reshape(-1, 3)[idx], rgb_o)
+
+
+def test_cfg4_4k_1024spp_as_4_sample_shards(gpu_ctx, cfg4_unsharded):
+    """Four SAMPLE shards: each rank's partial sums equal the oracle's sums over the same samples bit for bit; their total
+    (another order of f32 additions than one render) stays within rounding of the unsharded sums, and the quantised image
+    within one level."""
+    nx, ny, ns = CFG4
+    osc, rgb_full, acc_full, st_full, idx = cfg4_unsharded
+    upload_from_oracle(gpu_ctx, osc)
+    world = 4
+    total = np.zeros(acc_full.shape, np.float32)
+    rays = paths = 0
+    for rank in range(world):
+        r, a, st = gpu_ctx.render(rrt_amd.Context.params(nx, ny, ns, seed=0, shard_mode=rrt_amd.SHARD_SAMPLE, rank=rank, world=world))
+        acc_o, rgb_o, _ = osc.render_pixels(nx, ny, ns, 0, idx, k_begin=rank, k_step=world)
+        assert np.array_equal(bits(a.reshape(-1, 3)[idx]), bits(acc_o))
+        assert np.array_equal(r.reshape(-1, 3)[idx], rgb_o)      # the shard's own image: its sums over its 256 samples
+        total += a                                                # rank order, as a reduce onto rank 0 adds them
+        rays += st["rays"]
+        paths += st["paths"]
+    assert paths == nx * ny * ns and rays == st_full["rays"]
+    # tolerance: both orders add the same ns non-negative terms; each f32 addition errs by at most 2^-24 of the running sum,
+    # so either total is within ns * 2^-24 of the exact sum, relatively, and the two are within twice that of each other
+    assert np.allclose(total, acc_full, rtol=2 * ns * 2.0 ** -24, atol=0.0)
+    rel = np.abs(total - acc_full) / np.maximum(acc_full, 1e-30)
+    print(f"sample shards vs one render: max relative difference of the f32 sums {rel.max():.3e}, rms {np.sqrt((rel ** 2).mean()):.3e}")
+    from rrt_amd import multi
+    rgb = multi.finalize_numpy(total, ns)
+    diff = np.abs(rgb.astype(np.int16) - rgb_full.astype(np.int16))
+    assert diff.max() <= 1 and (diff != 0).mean() < 1e-3
 
 
 def test_large_scene_walks_the_hbm_bvh(gpu_ctx):
@@ -363,8 +441,8 @@ def test_large_scene_walks_the_hbm_bvh(gpu_ctx):
 
 
 def test_million_sphere_scene_spot(gpu_ctx):
-    """The big-scene configuration: 1000x1000 cells (~1 M spheres, ~2 M nodes), 1920x1080; spot-checked pixels at 8 spp."""
-    nx, ny, ns, half = 1920, 1080, 8, 500
+    """The big-scene configuration: 1000x1000 cells (~1 M spheres, ~2 M nodes), 1920x1080 at 256 spp; spot-checked pixels."""
+    nx, ny, ns, half = 1920, 1080, 256, 500
     hs = rrt_amd.HostScene(rrt_amd.SCENE_RANDOM_SPHERES, nx, ny, seed=0, half=half)
     assert hs.n_spheres > 990000
     gpu_ctx.upload_host_scene(hs)
@@ -395,7 +473,7 @@ def test_cli_renders_the_reference_default_scene(gpu_ctx, tmp_path):
     assert np.array_equal(np.frombuffer(raw[len(header):], np.uint8).reshape(ny, nx, 3), px)
 
 
-@pytest.mark.parametrize("name", ["chap12_1200x800x500", "book2chap2_1200x800x100"])
+@pytest.mark.parametrize("name", ["chap12_1200x800x500", "book2chap2_1200x800x500"])
 def test_full_size_image_digests(gpu_ctx, name):
     """Whole images at the headline sizes against digests of the oracle's renders (tests/golden/make_fullsize.py):
     every pixel of every row, f32 sums and RGB8, and the ray count."""
@@ -420,10 +498,10 @@ def test_full_size_image_digests(gpu_ctx, name):
 @pytest.mark.parametrize("kind,half", [(rrt_amd.SCENE_CHAP11, 0), (rrt_amd.SCENE_CHAP12, 0), (rrt_amd.SCENE_BOOK2CHAP2, 0),
                                        (rrt_amd.SCENE_RANDOM_SPHERES, 60), (rrt_amd.SCENE_RANDOM_SPHERES, 500)])
 def test_gpu_bvh_build_is_the_reference_tree(gpu_ctx, kind, half):
-    """rrt_build_bvh (level-synchronous, on the device) against the recursive host builder that mirrors Bvh::build_r:
-    every node, every bit.  chap11 takes the equal-count fallback (two concentric spheres), book2chap2 has moving boxes."""
-    hs = rrt_amd.HostScene(kind, 64, 64, seed=0, half=max(half, 11))
-    sp, mt, nd, cam = hs.export()
+    """rrt_build_bvh (level-synchronous, on the device) against the oracle's recursive Bvh::build_r restatement: every node,
+    every bit.  chap11 takes the equal-count fallback (two concentric spheres), book2chap2 has moving boxes."""
+    osc = OracleScene.build(kind, 64, 64, seed=0, half=max(half, 11))
+    sp, mt, nd, _ = osc.export()
     got = gpu_ctx.build_bvh(sp)
     assert got.shape == nd.shape
     assert np.array_equal(got, nd), f"{int((got != nd).any(axis=1).sum())} of {nd.shape[0]} nodes differ"
