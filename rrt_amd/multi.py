@@ -3,8 +3,10 @@
 Pixels and samples are independent in the reference (lib.rs:89-110), so a render shards with no exchange during
 rendering and one framebuffer combine at the end:
 
-  * tile shards   — rank r renders the 32x8 tiles t with t % world == r into a zero-filled full-size RGB8 / f32 image;
-                    images of disjoint pixel sets add up to the whole image (one reduce, bit-identical to a 1-GPU render);
+  * tile shards   — rank r renders the 32x8 tiles t with t % world == r; every rank packs the pixels it owns (RGB8 and, if
+                    wanted, the f32 sums) and rank 0 gathers them: each peer sends only its share over its own link
+                    (24.9 MB of RGB8 in all at 3840x2160) and the owner indices put them in place — bit-identical to a
+                    1-GPU render;
   * sample shards — rank r renders samples k with k % world == r of every pixel; the f32 sums are added (one reduce),
                     then quantised once (lib.rs:105-108).  Same rays as the 1-GPU render, another order of f32 additions.
 
@@ -48,10 +50,46 @@ def gpu_render_fn(ctx: "rrt_amd.Context", device) -> Callable:
     return fn
 
 
+def owned_pixels(nx: int, ny: int, mode: int, rank: int, world: int):
+    """Image pixel indices rank `rank` renders under `mode` (rrt_shard_pixels), as an int64 torch tensor on the CPU."""
+    import torch
+
+    return torch.from_numpy(rrt_amd.shard_pixels(nx, ny, mode, rank, world).astype(np.int64))
+
+
+def gather_tiles(buf, nx: int, ny: int, rank: int, world: int, dst: int = 0):
+    """Combines TILE shards of one image plane set.  `buf` is this rank's full-size buffer [ny*nx*3] (pixels it does not own
+    are ignored).  Every rank sends the pixels it owns, padded to the largest share; `dst` puts them in place and returns the
+    whole image, the other ranks return their own buffer."""
+    import torch
+    import torch.distributed as dist
+
+    counts = [int(rrt_amd.lib().rrt_shard_pixels(nx, ny, rrt_amd.SHARD_TILE, r, world, None)) for r in range(world)]
+    n_max = max(counts)
+    mine = owned_pixels(nx, ny, rrt_amd.SHARD_TILE, rank, world).to(buf.device)
+    packed = torch.zeros((n_max, 3), dtype=buf.dtype, device=buf.device)
+    packed[: counts[rank]] = buf.view(-1, 3)[mine]
+    via_host = buf.is_cuda and dist.get_backend() == "gloo"  # rehearsals on a process group without device collectives
+    if via_host:
+        packed = packed.cpu()
+    parts = [torch.empty_like(packed) for _ in range(world)] if rank == dst else None
+    dist.gather(packed, parts, dst=dst)
+    if rank != dst:
+        return buf
+    if via_host:
+        parts = [t.to(buf.device) for t in parts]
+    out = torch.zeros_like(buf).view(-1, 3)
+    for r in range(world):
+        idx = mine if r == rank else owned_pixels(nx, ny, rrt_amd.SHARD_TILE, r, world).to(buf.device)
+        out[idx] = parts[r][: counts[r]]
+    return out.view(-1)
+
+
 def render_sharded(render_fn: Callable, nx: int, ny: int, ns: int, seed: int, mode: int, rank: int, world: int, dst: int = 0,
-                   finalize: Optional[Callable] = None, max_depth: int = 50) -> Tuple[Optional[object], Optional[object], dict]:
+                   finalize: Optional[Callable] = None, max_depth: int = 50, want_accum: bool = True) -> Tuple[Optional[object], Optional[object], dict]:
     """Renders this rank's shard and combines on `dst`.  Returns (rgb8, accum, stats) — the image on `dst`, this rank's
-    partial buffers elsewhere.  `finalize(accum, ns) -> rgb8` quantises summed sample shards (GPU: Context.finalize)."""
+    partial buffers elsewhere.  `finalize(accum, ns) -> rgb8` quantises summed sample shards (GPU: Context.finalize).
+    `want_accum=False` skips the f32 sums of TILE shards (the reference returns RGB8 only, lib.rs:81)."""
     import torch
     import torch.distributed as dist
 
@@ -60,11 +98,16 @@ def render_sharded(render_fn: Callable, nx: int, ny: int, ns: int, seed: int, mo
     if world == 1:
         return rgb, acc, stats
     if mode == rrt_amd.SHARD_TILE:
-        # disjoint pixel sets, zero elsewhere: the sum is the image
-        dist.reduce(acc, dst=dst, op=dist.ReduceOp.SUM)
-        dist.reduce(rgb, dst=dst, op=dist.ReduceOp.SUM)
+        rgb = gather_tiles(rgb, nx, ny, rank, world, dst)
+        if want_accum and acc is not None:
+            acc = gather_tiles(acc, nx, ny, rank, world, dst)
     elif mode == rrt_amd.SHARD_SAMPLE:
-        dist.reduce(acc, dst=dst, op=dist.ReduceOp.SUM)
+        if acc.is_cuda and dist.get_backend() == "gloo":  # rehearsal without device collectives
+            host = acc.cpu()
+            dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM)
+            acc.copy_(host)
+        else:
+            dist.reduce(acc, dst=dst, op=dist.ReduceOp.SUM)
         if rank == dst:
             if finalize is None:
                 rgb = torch.from_numpy(finalize_numpy(acc.cpu().numpy(), ns)).to(acc.device)
