@@ -9,7 +9,7 @@ CXXFLAGS:= -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wextra -Wno-unused-pa
 
 LIB     := rrt_amd/librrt_amd.so
 OBJDIR  := build
-OBJS    := $(OBJDIR)/kernels.o $(OBJDIR)/noalloc.o $(OBJDIR)/bvh_gpu.o $(OBJDIR)/capi.o $(OBJDIR)/scene_layout.o $(OBJDIR)/rrt.o $(OBJDIR)/host_capi.o
+OBJS    := $(OBJDIR)/kernels.o $(OBJDIR)/noalloc.o $(OBJDIR)/bvh_gpu.o $(OBJDIR)/capi.o $(OBJDIR)/multi.o $(OBJDIR)/scene_layout.o $(OBJDIR)/rrt.o $(OBJDIR)/host_capi.o
 
 CLI     := rrt_amd/rrt
 
@@ -30,6 +30,9 @@ $(OBJDIR)/bvh_gpu.o: rrt_amd/csrc/bvh_gpu.hip include/rrt_amd.h | $(OBJDIR)
 $(OBJDIR)/capi.o: rrt_amd/csrc/capi.cpp rrt_amd/csrc/kernels.h rrt_amd/csrc/scene_layout.h include/rrt_amd.h | $(OBJDIR)
 	$(HIPCC) $(CXXFLAGS) -c $< -o $@
 
+$(OBJDIR)/multi.o: rrt_amd/csrc/multi.cpp rrt_amd/csrc/kernels.h include/rrt_amd.h | $(OBJDIR)
+	$(HIPCC) $(CXXFLAGS) -c $< -o $@
+
 $(OBJDIR)/scene_layout.o: rrt_amd/csrc/scene_layout.cpp rrt_amd/csrc/scene_layout.h include/rrt_amd.h | $(OBJDIR)
 	$(HIPCC) $(CXXFLAGS) -c $< -o $@
 
@@ -40,7 +43,7 @@ $(OBJDIR)/host_capi.o: rrt_amd/host/host_capi.cpp rrt_amd/host/rrt.hpp include/r
 	$(HIPCC) $(CXXFLAGS) -c $< -o $@
 
 $(LIB): $(OBJS)
-	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJS)
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJS) -ldl -lpthread
 
 $(OBJDIR)/rrt_cli.o: rrt_amd/host/rrt_cli.cpp rrt_amd/host/rrt.hpp include/rrt_amd.h include/rrt_amd_host.h | $(OBJDIR)
 	$(HIPCC) $(CXXFLAGS) -c $< -o $@

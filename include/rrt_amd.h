@@ -165,6 +165,19 @@ RRT_API int rrt_set_camera(rrt_ctx *ctx, const rrt_camera *camera);
 RRT_API int rrt_render(rrt_ctx *ctx, const rrt_render_params *params, uint8_t *out_rgb8, float *out_accum,
                        rrt_stats *stats, volatile uint64_t *progress);
 
+/* The same call on several GPUs of one node: ctxs[r] is rank r's context (one per GPU, each with the scene uploaded and the
+ * camera set), the whole image comes back in host memory as from rrt_render (lib.rs:73-81: one call, whole image).
+ * params->shard_mode picks how the ranks share the work: RRT_SHARD_TILE (or NONE: the default) — 32x8 tiles dealt
+ * round-robin, every rank sends the pixels it owns to rank 0's GPU (ncclSend/ncclRecv in one group; bit-identical to a
+ * one-GPU render); RRT_SHARD_SAMPLE — sample k goes to rank k mod n, the f32 sums are ncclReduce'd onto rank 0 and
+ * quantised there (another order of f32 additions: within rounding of the one-GPU sums).  shard_rank / shard_world are
+ * ignored.  stats are summed over the ranks (gpu_ms: the slowest rank).  One host thread per context for the call's
+ * duration; RCCL is loaded on first use, and not at all with n_ctx == 1.  Environment, for tests on a one-GPU machine:
+ * RRT_MULTI_LOOPBACK=1 lets contexts share a GPU and moves the shares with plain copies instead of RCCL;
+ * RRT_MULTI_FORCE_RCCL=1 sends even a single rank's share through RCCL. */
+RRT_API int rrt_render_multi(rrt_ctx *const *ctxs, uint32_t n_ctx, const rrt_render_params *params, uint8_t *out_rgb8,
+                             float *out_accum, rrt_stats *stats, volatile uint64_t *progress);
+
 /* Same, results left in device memory owned by the caller (hipMalloc'd / torch tensors):
  * d_rgb8 nx*ny*3 bytes (nullable), d_accum nx*ny*3 floats (nullable).  Runs on the context's
  * stream and returns after the stream has drained. */

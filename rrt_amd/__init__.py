@@ -100,6 +100,7 @@ def lib() -> C.CDLL:
     L.rrt_upload_scene.argtypes = [vp, C.POINTER(SphereSoa), C.POINTER(MaterialSoa), vp, u32]
     L.rrt_set_camera.argtypes = [vp, C.POINTER(Camera)]
     L.rrt_render.argtypes = [vp, C.POINTER(RenderParams), vp, vp, C.POINTER(Stats), vp]
+    L.rrt_render_multi.argtypes = [C.POINTER(vp), u32, C.POINTER(RenderParams), vp, vp, C.POINTER(Stats), vp]
     L.rrt_render_device.argtypes = [vp, C.POINTER(RenderParams), vp, vp, C.POINTER(Stats)]
     L.rrt_render_device_noalloc.argtypes = [vp, C.POINTER(RenderParams), vp, vp, C.POINTER(Stats)]
     L.rrt_finalize.argtypes = [vp, vp, u32, u32, vp]
@@ -322,6 +323,20 @@ class Context:
         _check(lib().rrt_intersect(self._h, n, org.ctypes.data, dirs.ctypes.data, tm.ctypes.data if tm is not None else None,
                                    t_min, t_max, out_t.ctypes.data, out_o.ctypes.data), "rrt_intersect")
         return out_t, out_o
+
+
+def render_multi(ctxs, p: RenderParams, want_accum: bool = True):
+    """rrt_render_multi over the given contexts (rank r = ctxs[r]): (rgb8 [ny,nx,3], accum or None, summed stats)."""
+    arr = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    rgb = np.zeros((p.ny, p.nx, 3), np.uint8)
+    acc = np.zeros((p.ny, p.nx, 3), np.float32) if want_accum else None
+    st = Stats()
+    done = C.c_uint64(0)
+    _check(lib().rrt_render_multi(arr, len(ctxs), C.byref(p), rgb.ctypes.data, acc.ctypes.data if want_accum else None, C.byref(st),
+                                  C.byref(done)), "rrt_render_multi")
+    d = st.as_dict()
+    d["progress"] = done.value
+    return rgb, acc, d
 
 
 def _soa(spheres9, material_id, mats6, nodes8):

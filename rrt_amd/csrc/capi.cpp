@@ -287,6 +287,7 @@ struct RenderTarget {
     void *d_rgb8 = nullptr, *d_accum = nullptr;      // device memory of the caller (nullable)
     rrt_stats *stats = nullptr;
     volatile uint64_t *progress = nullptr;           // finished pixels, updated while the call runs (lib.rs:109)
+    bool packed = false;                             // TILE shards: outputs hold only this rank's pixels, in rrt_shard_pixels order
     void *workspace = nullptr;                       // null: the context's own buffers, grown on demand; else: carve everything
     size_t workspace_bytes = 0;                      // out of this memory and allocate nothing
 };
@@ -370,8 +371,9 @@ int render_queued(rrt_ctx *c, const rrt_render_params &P, const RenderTarget &T,
         ns_local = rank < P.ns ? (P.ns - rank + world - 1) / world : 0;
     }
 
-    if (d_rgb8) HIP_TRY(hipMemsetAsync(d_rgb8, 0, (size_t)npix_img * 3, s));
-    if (d_accum) HIP_TRY(hipMemsetAsync(d_accum, 0, (size_t)npix_img * 12, s));
+    const size_t npix_out = T.packed ? npix : npix_img;
+    if (d_rgb8) HIP_TRY(hipMemsetAsync(d_rgb8, 0, npix_out * 3, s));
+    if (d_accum) HIP_TRY(hipMemsetAsync(d_accum, 0, npix_out * 12, s));
     HIP_TRY(hipEventRecord(c->ev0, s));
 
     const bool count = P.count_work != 0;
@@ -520,7 +522,7 @@ int render_queued(rrt_ctx *c, const rrt_render_params &P, const RenderTarget &T,
             launch_accumulate(s, accum, npix, rad, nb, s0 == 0);
         }
         // a SAMPLE shard's own RGB8 is the image of its samples alone: divide by their number, not by the whole job's
-        launch_finalize(s, accum, npix, d_map, ns_local, static_cast<uint8_t *>(d_rgb8), static_cast<float *>(d_accum));
+        launch_finalize(s, accum, npix, T.packed ? nullptr : d_map, ns_local, static_cast<uint8_t *>(d_rgb8), static_cast<float *>(d_accum));
         launch_reduce_stats(s, wstats, n_waves, static_cast<uint64_t *>(at(WS_STATS_OUT)));
         HIP_TRY(hipMemcpyAsync(c->h_stats, at(WS_STATS_OUT), kWaveStatWords * 8, hipMemcpyDeviceToHost, s));
     }
@@ -668,6 +670,17 @@ int render_in_workspace(rrt_ctx *ctx, const rrt_render_params *params, void *d_r
     return render_impl(ctx, params, T);
 }
 int context_device(const rrt_ctx *ctx) { return ctx ? ctx->device : -1; }
+hipStream_t context_stream(const rrt_ctx *ctx) { return ctx->stream; }
+// for multi.cpp: one rank's share of a sharded render, results left on the context's device; TILE shards come out packed
+int render_shard(rrt_ctx *ctx, const rrt_render_params *params, void *d_rgb8, void *d_accum, rrt_stats *stats, volatile uint64_t *progress, bool packed) {
+    try {
+        RenderTarget T;
+        T.d_rgb8 = d_rgb8; T.d_accum = d_accum; T.stats = stats; T.progress = progress; T.packed = packed;
+        return render_impl(ctx, params, T);
+    } catch (const std::exception &e) { return fail(RRT_ERR_OUT_OF_MEMORY, std::string("render: ") + e.what()); }
+}
+void shard_pixel_list(uint32_t nx, uint32_t ny, uint32_t rank, uint32_t world, std::vector<uint32_t> &out) { tile_pixels(nx, ny, rank, world, out); }
+const char *last_error_text() { return g_err.c_str(); }
 int set_error(int code, const std::string &msg) { return fail(code, msg); }
 
 }  // namespace rrt_amd

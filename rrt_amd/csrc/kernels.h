@@ -106,6 +106,11 @@ void launch_finalize_interleaved(hipStream_t s, const float *accum_rgb, uint32_t
 // reads their hit records back.  The walk itself is launch_extend, the kernel a render runs.
 void launch_intersect_setup(hipStream_t s, const PathState &P, uint32_t n, const float *org, const float *dir, const float *time);
 void launch_intersect_gather(hipStream_t s, const PathState &P, uint32_t n, float *out_t, uint32_t *out_obj);
+// image[map[l]] = packed[l] for the l-th pixel of a tile shard (3 components per pixel): puts a rank's share in place
+void launch_scatter_rgb8(hipStream_t s, const uint8_t *packed, const uint32_t *map, uint32_t n_pixels, uint8_t *image);
+void launch_scatter_f32(hipStream_t s, const float *packed, const uint32_t *map, uint32_t n_pixels, float *image);
+// dst[i] += src[i]
+void launch_add_f32(hipStream_t s, float *dst, const float *src, size_t n);
 void launch_reduce_stats(hipStream_t s, const uint64_t *wave_stats, uint32_t n_waves, uint64_t *out16);
 
 }  // namespace rrt_amd

@@ -1081,6 +1081,19 @@ __global__ void k_intersect_gather(PathState P, uint32_t n, float *out_t, uint32
     out_obj[i] = h.y == kPrimNone ? kPrimNone : (h.y & kLeafPrimMask);
 }
 
+template <class T>
+__global__ void k_scatter_pixels(const T *packed, const uint32_t *map, uint32_t n_values, T *image) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_values) return;
+    const uint32_t l = i / 3u, c = i - l * 3u;
+    image[(size_t)map[l] * 3u + c] = packed[i];
+}
+
+__global__ void k_add_f32(float *dst, const float *src, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
 __global__ void k_reduce_stats(const uint64_t *wave_stats, uint32_t n_waves, uint64_t *out16) {
     __shared__ uint64_t part[256];
     const uint32_t k = blockIdx.x;  // one counter per block
@@ -1190,6 +1203,20 @@ void launch_intersect_setup(hipStream_t s, const PathState &P, uint32_t n, const
 
 void launch_intersect_gather(hipStream_t s, const PathState &P, uint32_t n, float *out_t, uint32_t *out_obj) {
     hipLaunchKernelGGL(k_intersect_gather, dim3((n + 255u) / 256u), dim3(256), 0, s, P, n, out_t, out_obj);
+}
+
+void launch_scatter_rgb8(hipStream_t s, const uint8_t *packed, const uint32_t *map, uint32_t n_pixels, uint8_t *image) {
+    const uint32_t n = n_pixels * 3u;
+    if (n) hipLaunchKernelGGL((k_scatter_pixels<uint8_t>), dim3((n + 255u) / 256u), dim3(256), 0, s, packed, map, n, image);
+}
+
+void launch_scatter_f32(hipStream_t s, const float *packed, const uint32_t *map, uint32_t n_pixels, float *image) {
+    const uint32_t n = n_pixels * 3u;
+    if (n) hipLaunchKernelGGL((k_scatter_pixels<float>), dim3((n + 255u) / 256u), dim3(256), 0, s, packed, map, n, image);
+}
+
+void launch_add_f32(hipStream_t s, float *dst, const float *src, size_t n) {
+    if (n) hipLaunchKernelGGL(k_add_f32, dim3((unsigned)((n + 255u) / 256u)), dim3(256), 0, s, dst, src, n);
 }
 
 void launch_reduce_stats(hipStream_t s, const uint64_t *wave_stats, uint32_t n_waves, uint64_t *out16) {

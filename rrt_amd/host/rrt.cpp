@@ -3,6 +3,8 @@
 // contracts a*b+c, and ultraviolet's explicit mul_add calls are std::fmaf here.
 #include "rrt.hpp"
 
+#include <hip/hip_runtime_api.h>
+
 #include <chrono>
 #include <thread>
 
@@ -351,14 +353,31 @@ FlatScene flatten(const Scene &scene) {
 }
 
 // ------------------------------------------------------------------ pool + tracescene
-ThreadPool::ThreadPool(RttRng rng, int device) {
+ThreadPool::ThreadPool(RttRng rng, int device, int n_gpus) {
     seed_ = rng.next_u64();
-    if (rrt_create(device, &ctx_) != RRT_OK) throw std::runtime_error(std::string("init_pool_with_rng: ") + rrt_last_error());
+    std::vector<int> devices;
+    if (device >= 0 || n_gpus == 1) devices.push_back(device);
+    else {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) throw std::runtime_error("init_pool_with_rng: no HIP device");
+        if (n_gpus > 0 && n_gpus < n) n = n_gpus;
+        for (int d = 0; d < n; d++) devices.push_back(d);
+    }
+    for (int d : devices) {
+        rrt_ctx *c = nullptr;
+        if (rrt_create(d, &c) != RRT_OK) {
+            const std::string msg = rrt_last_error();
+            for (rrt_ctx *made : ctxs_) rrt_destroy(made);
+            ctxs_.clear();
+            throw std::runtime_error("init_pool_with_rng: " + msg);
+        }
+        ctxs_.push_back(c);
+    }
 }
-ThreadPool::~ThreadPool() { rrt_destroy(ctx_); }
-ThreadPool::ThreadPool(ThreadPool &&o) noexcept : ctx_(o.ctx_), seed_(o.seed_) { o.ctx_ = nullptr; }
+ThreadPool::~ThreadPool() { for (rrt_ctx *c : ctxs_) rrt_destroy(c); }
+ThreadPool::ThreadPool(ThreadPool &&o) noexcept : ctxs_(std::move(o.ctxs_)), seed_(o.seed_) { o.ctxs_.clear(); }
 
-ThreadPool init_pool_with_rng(RttRng rng, int device) { return ThreadPool(rng, device); }
+ThreadPool init_pool_with_rng(RttRng rng, int device, int n_gpus) { return ThreadPool(rng, device, n_gpus); }
 
 std::vector<uint8_t> tracescene(size_t nx, size_t ny, size_t ns, const Scene &scene, const Camera &camera, const ThreadPool &pool,
                                 std::atomic<size_t> &pdc) {
@@ -366,10 +385,12 @@ std::vector<uint8_t> tracescene(size_t nx, size_t ny, size_t ns, const Scene &sc
     const rrt_sphere_soa sp = flat.spheres();
     const rrt_material_soa mt = flat.materials();
     const std::vector<rrt_bvh_node> &nodes = scene.bvh.flatten();
-    if (rrt_upload_scene(pool.ctx(), &sp, &mt, nodes.data(), static_cast<uint32_t>(nodes.size())) != RRT_OK)
-        throw std::runtime_error(std::string("tracescene: ") + rrt_last_error());
     const rrt_camera cam = camera.flatten();
-    if (rrt_set_camera(pool.ctx(), &cam) != RRT_OK) throw std::runtime_error(std::string("tracescene: ") + rrt_last_error());
+    for (rrt_ctx *c : pool.contexts()) {  // the scene and the camera are replicated on every GPU of the pool
+        if (rrt_upload_scene(c, &sp, &mt, nodes.data(), static_cast<uint32_t>(nodes.size())) != RRT_OK)
+            throw std::runtime_error(std::string("tracescene: ") + rrt_last_error());
+        if (rrt_set_camera(c, &cam) != RRT_OK) throw std::runtime_error(std::string("tracescene: ") + rrt_last_error());
+    }
     rrt_render_params p{};
     p.nx = static_cast<uint32_t>(nx); p.ny = static_cast<uint32_t>(ny); p.ns = static_cast<uint32_t>(ns);
     p.max_depth = 50;  // lib.rs:58
@@ -390,7 +411,8 @@ std::vector<uint8_t> tracescene(size_t nx, size_t ny, size_t ns, const Scene &sc
             std::this_thread::sleep_for(std::chrono::milliseconds(20));
         }
     });
-    const int rc = rrt_render(pool.ctx(), &p, pixels.data(), nullptr, nullptr, &done);
+    // one GPU: rrt_render; several: tile shards, combined over RCCL on the first GPU (bit-identical either way)
+    const int rc = rrt_render_multi(pool.contexts().data(), static_cast<uint32_t>(pool.contexts().size()), &p, pixels.data(), nullptr, nullptr, &done);
     finished.store(true, std::memory_order_release);
     relay.join();
     if (rc != RRT_OK) throw std::runtime_error(std::string("tracescene: ") + rrt_last_error());

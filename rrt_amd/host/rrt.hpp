@@ -154,21 +154,24 @@ std::pair<Scene, Camera> book2_chap2_scene(size_t nx, size_t ny, RttRng &rng);  
 // camera scaled by half/11.  half = 500 gives the one-million-sphere traversal stress scene.
 std::pair<Scene, Camera> random_spheres_scene(size_t nx, size_t ny, RttRng &rng, int half);
 
-// ---- threadpool.rs:11-27: what runs the per-pixel work.  Here: one GPU plus the base generator
-//      from which every (pixel, sample) stream is derived. ----
+// ---- threadpool.rs:11-27: what runs the per-pixel work.  Here: the GPUs of the node (or one of them) plus the base
+//      generator from which every (pixel, sample) stream is derived. ----
 class ThreadPool {
 public:
-    ThreadPool(RttRng rng, int device);
+    // device >= 0: that GPU alone.  device < 0: the first n_gpus GPUs of the node, all of them when n_gpus is 0.
+    ThreadPool(RttRng rng, int device, int n_gpus = 1);
     ~ThreadPool();
     ThreadPool(ThreadPool &&o) noexcept;
     ThreadPool(const ThreadPool &) = delete;
-    rrt_ctx *ctx() const { return ctx_; }
+    rrt_ctx *ctx() const { return ctxs_.empty() ? nullptr : ctxs_[0]; }
+    const std::vector<rrt_ctx *> &contexts() const { return ctxs_; }
     uint64_t stream_seed() const { return seed_; }
 private:
-    rrt_ctx *ctx_ = nullptr;
+    std::vector<rrt_ctx *> ctxs_;
     uint64_t seed_ = 0;
 };
-ThreadPool init_pool_with_rng(RttRng rng, int device = -1);
+// device < 0 and n_gpus == 1: the current GPU, as a one-GPU machine would
+ThreadPool init_pool_with_rng(RttRng rng, int device = -1, int n_gpus = 1);
 
 // Flattened scene in the interchange form of include/rrt_amd.h; owns the planes it points at.
 struct FlatScene {

@@ -2,12 +2,13 @@
 // saves `o.ppm`.
 //
 //   rrt [-r|--resolution WxH] [-s|--samples N] [-e|--seed SEED] [-m|--random] [--scene chap11|chap12|book2chap2]
-//       [-o FILE] [--device N]
+//       [-o FILE] [--device N] [--gpus N]
 //
 // Same defaults (1200x800, 10 samples, seed 0), same messages on stderr, same order of events: generator, scene,
 // pool, render, image.  The progress line is printed by a side thread that polls the pixel counter once a second like
 // the reference's progress bar (main.rs:80-94); the counter jumps to nx*ny when the render call returns.
-// --scene, -o and --device are additions; the reference hard-wires book2chap2 (main.rs:96) and o.ppm (main.rs:101).
+// --scene, -o, --device and --gpus are additions; the reference hard-wires book2chap2 (main.rs:96) and o.ppm (main.rs:101).
+// Without --device the render is shared by all GPUs of the node (--gpus N: the first N), as the reference uses all cores.
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -56,7 +57,8 @@ void usage() {
                  "  -m, --random                   use a random rng seed\n"
                  "      --scene <name>             chap11, chap12 or book2chap2 [default: book2chap2]\n"
                  "  -o <file>                      output image [default: o.ppm]\n"
-                 "      --device <n>               GPU to render on [default: the current one]\n");
+                 "      --device <n>               render on this GPU alone\n"
+                 "      --gpus <n>                 render on the first n GPUs of the node [default: all]\n");
 }
 
 }  // namespace
@@ -64,7 +66,7 @@ void usage() {
 int main(int argc, char **argv) {
     const char *resolution = "1200x800", *samples = "10", *seed = "0", *scene_name = "book2chap2", *out = "o.ppm";
     bool random_seed = false;
-    int device = -1;
+    int device = -1, n_gpus = 0;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto value = [&](const char *&dst) {
@@ -78,6 +80,7 @@ int main(int argc, char **argv) {
         else if (a == "--scene") value(scene_name);
         else if (a == "-o") value(out);
         else if (a == "--device") { const char *d = nullptr; value(d); device = std::atoi(d); }
+        else if (a == "--gpus") { const char *d = nullptr; value(d); n_gpus = std::atoi(d); }
         else if (a == "-h" || a == "--help") { usage(); return 0; }
         else { std::fprintf(stderr, "error: unexpected argument '%s'\n", a.c_str()); usage(); return 2; }
     }
@@ -113,7 +116,7 @@ int main(int argc, char **argv) {
         auto sc = sn == "chap11" ? rrt::chap11_scene(w, h) : sn == "chap12" ? rrt::chap12_scene(w, h, rng)
                 : sn == "book2chap2" ? rrt::book2_chap2_scene(w, h, rng)
                 : throw std::runtime_error("unknown scene '" + sn + "'");
-        rrt::ThreadPool pool = rrt::init_pool_with_rng(rng, device);
+        rrt::ThreadPool pool = rrt::init_pool_with_rng(rng, device, device >= 0 ? 1 : n_gpus);
         const auto t0 = std::chrono::steady_clock::now();
         const std::vector<uint8_t> pixels = rrt::tracescene(w, h, static_cast<size_t>(spp), sc.first, sc.second, pool, pxcount);
         const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

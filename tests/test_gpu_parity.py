@@ -568,6 +568,69 @@ def test_device_buffer_entry_points(gpu_ctx):
     assert diff.max() <= 1 and (diff != 0).mean() < 0.01
 
 
+def test_render_multi_one_call_whole_image(gpu_ctx, monkeypatch):
+    """rrt_render_multi (lib.rs:73-81: one call, the whole image back) over 1, 2 and 3 contexts.  This machine has one GPU, so
+    the contexts share it and the shares travel by plain copies (RRT_MULTI_LOOPBACK); what is under test is the sharding,
+    the packed tile shares, their placement, the sample-shard sum and the summed counters.  With one context and
+    RRT_MULTI_FORCE_RCCL the share goes through real RCCL calls (a one-rank communicator: send/recv to itself, reduce)."""
+    nx, ny, ns = 150, 70, 10   # not a multiple of the 32x8 tile
+    osc = OracleScene.build(SCENES["book2chap2"], nx, ny, seed=0)
+    ref = osc.render(nx, ny, ns, seed=3, threads=8)
+    ctxs = [gpu_ctx, rrt_amd.Context(0), rrt_amd.Context(0)]
+    try:
+        for c in ctxs:
+            upload_from_oracle(c, osc)
+        # one context: the plain render
+        got = rrt_amd.render_multi(ctxs[:1], rrt_amd.Context.params(nx, ny, ns, seed=3))
+        assert_same_image(got, ref)
+        assert got[2]["progress"] == nx * ny
+        monkeypatch.setenv("RRT_MULTI_LOOPBACK", "1")
+        for n in (2, 3):
+            got = rrt_amd.render_multi(ctxs[:n], rrt_amd.Context.params(nx, ny, ns, seed=3, shard_mode=rrt_amd.SHARD_TILE, count_work=True))
+            assert_same_image(got, ref)                      # tile shards: bit-identical, f32 sums included
+            for key in ("inner_visits", "leaf_tests", "sky_misses"):
+                assert got[2][key] == ref[2][key], key       # counters summed over the ranks
+            rgb, acc, st = rrt_amd.render_multi(ctxs[:n], rrt_amd.Context.params(nx, ny, ns, seed=3, shard_mode=rrt_amd.SHARD_SAMPLE))
+            assert st["rays"] == ref[2]["rays"] and st["paths"] == nx * ny * ns
+            assert np.allclose(acc, ref[1], rtol=2 * ns * 2.0 ** -24, atol=0.0)   # another order of the same ns additions
+            diff = np.abs(rgb.astype(int) - ref[0].astype(int))
+            assert diff.max() <= 1 and (diff != 0).mean() < 0.01
+        rgb_only = rrt_amd.render_multi(ctxs[:2], rrt_amd.Context.params(nx, ny, ns, seed=3), want_accum=False)   # NONE = tiles
+        assert np.array_equal(rgb_only[0], ref[0])
+        monkeypatch.delenv("RRT_MULTI_LOOPBACK")
+        monkeypatch.setenv("RRT_MULTI_FORCE_RCCL", "1")
+        got = rrt_amd.render_multi(ctxs[:1], rrt_amd.Context.params(nx, ny, ns, seed=3, shard_mode=rrt_amd.SHARD_TILE))
+        assert_same_image(got, ref)
+        got = rrt_amd.render_multi(ctxs[:1], rrt_amd.Context.params(nx, ny, ns, seed=3, shard_mode=rrt_amd.SHARD_SAMPLE))
+        assert_same_image(got, ref)                          # one rank: the reduce changes nothing
+        monkeypatch.delenv("RRT_MULTI_FORCE_RCCL")
+        with pytest.raises(rrt_amd.RrtError, match="one GPU"):
+            rrt_amd.render_multi(ctxs[:2], rrt_amd.Context.params(nx, ny, ns, seed=3))   # RCCL cannot put two ranks on one GPU
+    finally:
+        for c in ctxs[1:]:
+            c.close()
+
+
+def test_render_multi_on_two_gpus_over_rccl(gpu_ctx):
+    """The same call on two real GPUs, shares moved by RCCL.  Skipped where the machine has one GPU."""
+    try:
+        second = rrt_amd.Context(1)
+    except rrt_amd.RrtError:
+        pytest.skip("one GPU here")
+    try:
+        nx, ny, ns = 150, 70, 10
+        osc = OracleScene.build(SCENES["chap12"], nx, ny, seed=0)
+        ref = osc.render(nx, ny, ns, seed=3, threads=8)
+        for c in (gpu_ctx, second):
+            upload_from_oracle(c, osc)
+        got = rrt_amd.render_multi([gpu_ctx, second], rrt_amd.Context.params(nx, ny, ns, seed=3, shard_mode=rrt_amd.SHARD_TILE))
+        assert_same_image(got, ref)
+        rgb, acc, st = rrt_amd.render_multi([gpu_ctx, second], rrt_amd.Context.params(nx, ny, ns, seed=3, shard_mode=rrt_amd.SHARD_SAMPLE))
+        assert st["rays"] == ref[2]["rays"] and np.allclose(acc, ref[1], rtol=2 * ns * 2.0 ** -24, atol=0.0)
+    finally:
+        second.close()
+
+
 def test_build_bvh_argument_errors(gpu_ctx):
     import ctypes as C
     sp = np.zeros((3, 9), np.float32); sp[:, 0] = [0, 1, 2]; sp[:, 3] = [0, 1, 2]; sp[:, 8] = 0.3
