@@ -237,8 +237,10 @@ int upload_scene_impl(rrt_ctx *c, const rrt_sphere_soa *sp, const rrt_material_s
     c->sd.u_time0 = L.u_time0;
     c->sd.u_dt = L.u_dt;
     c->sd.small_nodes = L.small_nodes.empty() ? nullptr : c->small_nodes.as<uint4>();
-    c->sd.small_words = L.small_words;
+    c->sd.small_bytes = L.small_bytes;
     c->sd.small_root = L.small_root;
+    c->sd.small_end = L.small_end;
+    c->sd.small_leaf_links = L.small_leaf_links;
     c->sd.n_nodes = L.n_nodes;
     c->sd.n_spheres = L.n_spheres;
     c->sd.top_nodes = L.top_nodes.empty() ? nullptr : c->top_nodes.as<uint4>();

@@ -33,8 +33,10 @@ struct SceneDev {
     float u_time0, u_dt;
     // compact copy for LDS residency (null when the scene does not qualify; see scene_layout.h)
     const uint4 *small_nodes;
-    uint32_t small_words;   // words per node
-    uint32_t small_root;    // reference of the root
+    uint32_t small_bytes;       // size of the image (the device copy is padded to a multiple of 16 bytes)
+    uint32_t small_root;        // reference (byte offset) of the root
+    uint32_t small_end;         // the reference that ends a walk; inner nodes lie below it, leaves above
+    uint32_t small_leaf_links;  // byte offset of the eight 16-bit exit links inside a leaf
     uint32_t n_nodes;
     uint32_t n_spheres;
     // copy of the top levels of the tree for scenes without a compact copy (references with kRefTopBit index it), or null

@@ -136,10 +136,9 @@ struct RayCtx {
     float time, f_ray;
     float tmin, tmax;
     uint32_t oct;   // bit k set: 1/d[k] < 0 (acceleration.rs:230-231)
-    // for the compact LDS nodes: byte offset inside a node of the (near, far) plane pair of each axis, and a word whose
-    // 5-bit field at 5 * axis (repeated 16 bits up) is the bit position of the near child's reference in node word 9
-    uint32_t cx, cy, cz, sel;
-    uint32_t lds_base, oct2;  // set by LdsStore::prepare
+    // for the compact LDS image: byte offset inside an inner node of the (near, far) plane pair of each axis and of the
+    // (near child | exit) word of the ray's octant, and inside a leaf of the octant's exit link
+    uint32_t cx, cy, cz, link, leaf_link;
     uint32_t best;  // store-specific handle of the closest leaf so far
 };
 
@@ -149,8 +148,8 @@ DEV void ray_finish(RayCtx &r, float tmin, float tmax, const SceneDev &S, bool u
     const uint32_t nx = r.ox.y < 0.0f ? 1u : 0u, ny = r.oy.y < 0.0f ? 1u : 0u, nz = r.oz.y < 0.0f ? 1u : 0u;  // acceleration.rs:230-231
     r.oct = nx | (ny << 1) | (nz << 2);
     r.cx = nx << 2; r.cy = 12u + (ny << 2); r.cz = 24u + (nz << 2);
-    const uint32_t sel15 = (nx ? 4u + kRef14Bits : 4u) | ((ny ? 4u + kRef14Bits : 4u) << 5) | ((nz ? 4u + kRef14Bits : 4u) << 10);
-    r.sel = sel15 | (sel15 << 16);
+    r.link = kSmallLinkOffset + (r.oct << 2);
+    r.leaf_link = S.small_leaf_links + (r.oct << 1);
     r.f_ray = uniform_times ? (r.time - S.u_time0) / S.u_dt : 0.0f;  // center_at's factor when every moving sphere shares its shutter interval
     r.tmin = tmin;
     r.tmax = tmax;
@@ -173,12 +172,12 @@ DEV uint4 load4(Ptr p, uint32_t i) { const u32x4 v = p[i]; return make_uint4(v.x
 
 template <bool MOVING, class TopPtr = HbmNodePtr>
 struct HbmStore {
-    static constexpr uint32_t kEnd = kRefEnd;
     const SceneDev &S;
     TopPtr top;  // the copy of the top of the tree that references with kRefTopBit index: in HBM, or (k_extend_top) in LDS
     DEV explicit HbmStore(const SceneDev &s) : S(s), top(reinterpret_cast<HbmNodePtr>(s.top_nodes)) {}
     DEV HbmStore(const SceneDev &s, TopPtr top_copy) : S(s), top(top_copy) {}
     DEV uint32_t root() const { return S.root_ref; }
+    DEV uint32_t end() const { return kRefEnd; }  // references order as inner < end < leaf
     // the first 32 bytes of the node and its exit link for octant `oct`
     DEV void fetch(uint32_t ref, uint32_t oct, uint4 &n0, uint4 &n1, uint32_t &exit_ref) const {
         const uint32_t idx = ref & kRefIndexMask;
@@ -222,59 +221,39 @@ struct HbmStore {
     DEV uint32_t prim_of(uint32_t handle) const { return handle; }
 };
 
+// The compact image in LDS (scene_layout.h): a reference is a node's LDS address, inner nodes lie below `end`, leaves above.
 template <bool MOVING>
 struct LdsStore {
-    static constexpr uint32_t kEnd = kRef14End;
-    const char *lds;
-    uint32_t root14;
-    DEV LdsStore(const void *p, uint32_t r) : lds(static_cast<const char *>(p)), root14(r) {}
-    DEV uint32_t root() const { return root14; }
+    uint32_t root16, end16;
+    DEV LdsStore(uint32_t root, uint32_t end) : root16(root), end16(end) {}
+    DEV uint32_t root() const { return root16; }
+    DEV uint32_t end() const { return end16; }
     DEV bool uniform_times() const { return MOVING; }  // the compact copy exists only for scenes with one shutter interval
-    // a reference is the node's offset in 8-byte units (bit 13: leaf)
-    DEV const char *node_at(uint32_t off8) const { return lds + (off8 << 3); }
     typedef const __attribute__((address_space(3))) uint32_t *LdsWordPtr;
-    DEV static uint32_t lshl3_add(uint32_t a, uint32_t b) {
-        uint32_t r;
-        asm("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(r) : "v"(a), "v"(b));
-        return r;
-    }
-    DEV static f32x2 pair_at(uint32_t lds_addr) {
-        const __attribute__((address_space(3))) float *f = reinterpret_cast<const __attribute__((address_space(3))) float *>(static_cast<uintptr_t>(lds_addr));
-        return f32x2{f[0], f[1]};
-    }
-    // folds the LDS address of the node array into the per-ray byte offsets inner() adds to a node reference
-    DEV void prepare(RayCtx &r) const {
-        const uint32_t base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) char *)lds));
-        r.cx += base; r.cy += base; r.cz += base; r.lds_base = base; r.oct2 = base + 2u * r.oct;
-    }
+    typedef const __attribute__((address_space(3))) float *LdsFloatPtr;
+    typedef const __attribute__((address_space(3))) uint16_t *LdsHalfPtr;
+    DEV static LdsWordPtr words(uint32_t lds_addr) { return reinterpret_cast<LdsWordPtr>(static_cast<uintptr_t>(lds_addr)); }
+    DEV static LdsFloatPtr floats(uint32_t lds_addr) { return reinterpret_cast<LdsFloatPtr>(static_cast<uintptr_t>(lds_addr)); }
+    DEV static f32x2 pair_at(uint32_t lds_addr) { const LdsFloatPtr f = floats(lds_addr); return f32x2{f[0], f[1]}; }
+    DEV void prepare(RayCtx &) const {}
     // The box is stored per axis as (min, max, min): the pair that starts one word in is (max, min), so a ray that is
-    // negative along the axis reads (near, far) directly, with an address instead of a select.
-    DEV void inner(uint32_t cur, const RayCtx &r, f32x2 &bx, f32x2 &by, f32x2 &bz, uint32_t &near_ref, uint32_t &exit_ref) const {
-        // five LDS addresses, each one shift-and-add from the reference (prepare() has put the LDS address of the node
-        // array into the ray's offsets)
-        const uint32_t ax = lshl3_add(cur, r.cx), ay = lshl3_add(cur, r.cy), az = lshl3_add(cur, r.cz);
-        const uint32_t aw = lshl3_add(cur, r.lds_base), ae = lshl3_add(cur, r.oct2);
-        bx = pair_at(ax); by = pair_at(ay); bz = pair_at(az);
-        const uint32_t w9 = *reinterpret_cast<LdsWordPtr>(static_cast<uintptr_t>(aw + 36u));
-        exit_ref = *reinterpret_cast<const __attribute__((address_space(3))) uint16_t *>(static_cast<uintptr_t>(ae + 40u));
-        // word 9 = 5 * axis | left << 4 | right << 18; only the low five bits of a shift count (v_bfe_u32) count
-        const uint32_t at = __builtin_amdgcn_ubfe(r.sel, w9, 5u);
-        near_ref = __builtin_amdgcn_ubfe(w9, at, kRef14Bits);
+    // negative along the axis reads (near, far) directly, with an address instead of a select.  `links` comes back as
+    // near child | exit link << 16 for the ray's octant.
+    DEV void inner(uint32_t cur, const RayCtx &r, f32x2 &bx, f32x2 &by, f32x2 &bz, uint32_t &links) const {
+        bx = pair_at(cur + r.cx); by = pair_at(cur + r.cy); bz = pair_at(cur + r.cz);
+        links = *words(cur + r.link);
     }
     DEV void leaf(uint32_t cur, const RayCtx &r, V3 &c, float &rr, uint32_t &handle, uint32_t &exit_ref) const {
-        const uint32_t off8 = cur & (kRef14LeafBit - 1u);
-        const char *node = node_at(off8);
-        const uint2 n0 = *reinterpret_cast<const uint2 *>(node), n1 = *reinterpret_cast<const uint2 *>(node + 8);
-        exit_ref = *reinterpret_cast<const uint16_t *>(node + 40u + 2u * r.oct);
-        c = mk(u2f(n0.x), u2f(n0.y), u2f(n1.x));
-        rr = u2f(n1.y);
-        handle = off8;
-        if (MOVING) {
-            const float *m = reinterpret_cast<const float *>(node + 24);  // centre1 - centre0, zero words for a sphere at rest
-            if (*reinterpret_cast<const uint32_t *>(node + 20) & 1u) c = add(c, scale(r.f_ray, mk(m[0], m[1], m[2])));
+        const LdsFloatPtr f = floats(cur);
+        exit_ref = *reinterpret_cast<LdsHalfPtr>(static_cast<uintptr_t>(cur + r.leaf_link));
+        c = mk(f[0], f[1], f[2]);
+        rr = f[3];
+        handle = cur;
+        if (MOVING) {  // centre1 - centre0 behind the flag word, zero words for a sphere at rest
+            if (words(cur)[5] & 1u) c = add(c, scale(r.f_ray, mk(f[6], f[7], f[8])));
         }
     }
-    DEV uint32_t prim_of(uint32_t handle) const { return *reinterpret_cast<const uint32_t *>(node_at(handle) + 16); }
+    DEV uint32_t prim_of(uint32_t handle) const { return words(handle)[4]; }
 };
 
 // Aabb::intersect (acceleration.rs:60-84) against the current t_max, then the step of acceleration.rs:250-267.
@@ -289,11 +268,8 @@ DEV f32x2 slab_pair(f32x2 box, f32x2 oi) {
     return t;
 }
 
-template <class Store>
-DEV uint32_t visit_inner(const Store &st, uint32_t cur, const RayCtx &r) {
-    f32x2 bx, by, bz;
-    uint32_t near_ref, exit_ref;
-    st.inner(cur, r, bx, by, bz, near_ref, exit_ref);
+// t0 <= t1 of the slab test, from the three (near, far) plane pairs
+DEV void slab_interval(f32x2 bx, f32x2 by, f32x2 bz, const RayCtx &r, float &t0, float &t1) {
     const f32x2 tx = slab_pair(bx, r.ox), ty = slab_pair(by, r.oy), tz = slab_pair(bz, r.oz);
     const float tnx = tx.x, tny = ty.x, tnz = tz.x;
     const float tfx = tx.y, tfy = ty.y, tfz = tz.y;
@@ -301,13 +277,36 @@ DEV uint32_t visit_inner(const Store &st, uint32_t cur, const RayCtx &r) {
     // the smallest of the three gives bit for bit the smallest of the three scaled values.  The min/max chains are
     // spelled as instructions because the compiler cannot know that the packed results above are already canonical
     // and would re-canonicalise each of them first.
-    float n3, t0, f3, t1;
+    float n3, f3;
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(n3) : "v"(tnx), "v"(tny), "v"(tnz));
     asm("v_max_f32 %0, %1, %2" : "=v"(t0) : "v"(n3), "v"(r.tmin));
     asm("v_min3_f32 %0, %1, %2, %3" : "=v"(f3) : "v"(tfx), "v"(tfy), "v"(tfz));
     const float f3s = f3 * RRT_FAR_SCALE;
     asm("v_min_f32 %0, %1, %2" : "=v"(t1) : "v"(f3s), "v"(r.tmax));
+}
+
+template <bool MOVING, class TopPtr>
+DEV uint32_t visit_inner(const HbmStore<MOVING, TopPtr> &st, uint32_t cur, const RayCtx &r) {
+    f32x2 bx, by, bz;
+    uint32_t near_ref, exit_ref;
+    st.inner(cur, r, bx, by, bz, near_ref, exit_ref);
+    float t0, t1;
+    slab_interval(bx, by, bz, r, t0, t1);
     return (t0 <= t1) ? near_ref : exit_ref;  // the far child is the near child's exit link
+}
+
+template <bool MOVING>
+DEV uint32_t visit_inner(const LdsStore<MOVING> &st, uint32_t cur, const RayCtx &r) {
+    f32x2 bx, by, bz;
+    uint32_t links;
+    st.inner(cur, r, bx, by, bz, links);
+    float t0, t1;
+    slab_interval(bx, by, bz, r, t0, t1);
+    // low half of `links` (the near child) if the box is hit, high half (the exit link) if not, in one instruction
+    uint32_t next;
+    asm("v_cmp_le_f32 vcc, %1, %2\n\ts_nop 1\n\tv_cndmask_b32_sdwa %0, %3, %3, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0"
+        : "=v"(next) : "v"(t0), "v"(t1), "v"(links) : "vcc");
+    return next;
 }
 
 // Sphere::hit (sphere.rs:68-85); the Hit record itself is rebuilt in shade, for the final hit only.  (Deferring the
@@ -358,6 +357,7 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
     if (count == 0) return;
     uint32_t n_taken = 0;
     const bool uniform_times = st.uniform_times();
+    const uint32_t kEnd = st.end();  // wave-uniform: references below it are inner nodes, above it leaves
     uint32_t n_inner = 0, n_leaf = 0;
     uint32_t d_desc_iters = 0, d_desc_lanes = 0, d_leaf_iters = 0, d_leaf_lanes = 0, d_retires = 0, d_retire_lanes = 0;  // COUNT only
     // (own list that is not full) the lane's column of the list, read up front so that no ray load waits for a list load
@@ -375,9 +375,9 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     RayCtx r;
     ray_load(r, make_float4(0, 0, 0, 0), make_float4(1, 1, 1, 0), make_float4(1, 1, 1, 3), 0.001f, __FLT_MAX__, S, false);
-    uint32_t cur = Store::kEnd;
+    uint32_t cur = kEnd;
     for (;;) {
-        const bool idle = cur == Store::kEnd;
+        const bool idle = cur == kEnd;
         const uint64_t idle_m = __ballot(idle);
         const uint64_t ready = __ballot(idle && (has || head < count));
         if (~idle_m == 0ull || (uint32_t)__popcll(ready) >= retire_min) {
@@ -417,7 +417,7 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
         }
         // descend until no lane is at an inner node, or enough lanes wait at a sphere for a test to be worth a pass
         for (;;) {  // two box tests per look at the number of lanes waiting at a sphere
-            bool at_inner = cur < Store::kEnd;
+            bool at_inner = cur < kEnd;
             uint64_t im = __ballot(at_inner);
             if (im == 0ull) break;
             if (COUNT) { d_desc_iters++; d_desc_lanes += (uint32_t)__popcll(im); }
@@ -425,7 +425,7 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
                 if (COUNT) n_inner++;
                 cur = visit_inner(st, cur, r);
             }
-            at_inner = cur < Store::kEnd;
+            at_inner = cur < kEnd;
             im = __ballot(at_inner);
             if (im == 0ull) break;
             if (COUNT) { d_desc_iters++; d_desc_lanes += (uint32_t)__popcll(im); }
@@ -433,10 +433,10 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
                 if (COUNT) n_inner++;
                 cur = visit_inner(st, cur, r);
             }
-            if ((uint32_t)__popcll(__ballot(cur > Store::kEnd)) >= leaf_min) break;
+            if ((uint32_t)__popcll(__ballot(cur > kEnd)) >= leaf_min) break;
         }
-        if (COUNT) { const uint64_t lm = __ballot(cur > Store::kEnd); if (lm) { d_leaf_iters++; d_leaf_lanes += (uint32_t)__popcll(lm); } }
-        if (cur > Store::kEnd) {
+        if (COUNT) { const uint64_t lm = __ballot(cur > kEnd); if (lm) { d_leaf_iters++; d_leaf_lanes += (uint32_t)__popcll(lm); } }
+        if (cur > kEnd) {
             if (COUNT) n_leaf++;
             cur = visit_leaf(st, cur, r);
         }
@@ -481,7 +481,7 @@ template <bool MOVING, bool COUNT>
 __global__ __launch_bounds__(kLdsBlockThreads, 8) void k_extend_lds(SceneDev S, PathState P, uint32_t retire_min, uint32_t leaf_min,
                                                                   uint64_t *wave_stats) {
     extern __shared__ uint4 lds4[];
-    const uint32_t n_vec = (S.n_nodes * kSmallWords + 3u) / 4u;  // 16-byte pieces; the host pads the array to a whole number of them
+    const uint32_t n_vec = (S.small_bytes + 15u) / 16u;  // 16-byte pieces; the host pads the image to a whole number of them
     // next position of the workgroup's ray pool; sum of the workgroup's list lengths.  Behind the nodes, so that the nodes
     // start at LDS address 0 and a node reference needs no base added
     uint32_t *pool = reinterpret_cast<uint32_t *>(lds4 + n_vec);
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(kLdsBlockThreads, 8) void k_extend_lds(SceneDev S, 
     const uint32_t n_lists = min(kLdsBlockThreads / 64u, P.wave_end - wave0);
     const uint32_t total = rfl(pool[1]);  // the same for every lane: say so, and the list bookkeeping stays in scalar registers
     const bool pooled = total == n_lists * kWaveSlots;
-    const LdsStore<MOVING> st(lds4, S.small_root);
+    const LdsStore<MOVING> st(S.small_root, S.small_end);  // the image starts at LDS address 0: a reference is an LDS address
     extend_wave<LdsStore<MOVING>, MOVING, COUNT>(st, S, P, wave, lane, retire_min, leaf_min, wave_stats, own_count, pooled ? &pool[0] : nullptr,
                                                  wave0 * kWaveSlots, total);
 }
@@ -1121,7 +1121,7 @@ void launch_extend(hipStream_t s, const SceneDev &S, const PathState &P, bool mo
     if (S.small_nodes) {  // scene fits in LDS
         const uint32_t waves_per_block = kLdsBlockThreads / 64u;
         const dim3 g((P.wave_end - P.wave_begin + waves_per_block - 1u) / waves_per_block), b(kLdsBlockThreads);
-        const size_t lds = (((size_t)S.n_nodes * S.small_words * 4u + 15u) & ~(size_t)15u) + 16u;  // nodes, then the pool counters
+        const size_t lds = (((size_t)S.small_bytes + 15u) & ~(size_t)15u) + 16u;  // the image, then the pool counters
         if (moving) {
             if (count) hipLaunchKernelGGL((k_extend_lds<true, true>), g, b, lds, s, S, P, retire_min, leaf_min, wave_stats);
             else hipLaunchKernelGGL((k_extend_lds<true, false>), g, b, lds, s, S, P, retire_min, leaf_min, wave_stats);

@@ -184,33 +184,52 @@ int build_scene_layout(const rrt_sphere_soa *sp, const rrt_material_soa *mt, con
 
     // ---- compact copy for LDS residency (layout in scene_layout.h) ----
     const bool moving = (out.flags & kSceneHasMoving) != 0;
-    const uint32_t sw = kSmallWords;
     const bool times_ok = !moving || (out.flags & kSceneUniformTimes) != 0;
-    if (times_ok && static_cast<size_t>(n_nodes) * (sw / 2u) < kRef14End && static_cast<size_t>(n_nodes) * sw * 4 <= kSmallLdsBudget) {
-        auto ref14 = [&](uint32_t r) -> uint32_t {
-            if (r == kRefEnd) return kRef14End;
-            return (r & kRefIndexMask) * (sw / 2u) | ((r & kRefLeafBit) ? kRef14LeafBit : 0u);
-        };
-        out.small_words = sw;
-        out.small_nodes.assign(static_cast<size_t>(n_nodes) * sw, 0u);
+    uint32_t n_inner = 0, n_leaf = 0;
+    for (uint32_t i = 0; i < n_nodes; i++) { if (out.node_kind[i] == 1) n_inner++; else if (out.node_kind[i] == 2) n_leaf++; }
+    const uint32_t leaf_bytes = moving ? kSmallLeafBytesMoving : kSmallLeafBytes;
+    const uint64_t end_off = static_cast<uint64_t>(n_inner) * kSmallInnerBytes;
+    const uint64_t total = end_off + 4u + static_cast<uint64_t>(n_leaf) * leaf_bytes;
+    if (times_ok && total <= kSmallLdsBudget) {
+        // byte offset of every reachable node: inner nodes and leaves numbered separately, each kind in node order
+        std::vector<uint32_t> off(n_nodes, 0u);
+        uint32_t ii = 0, li = 0;
         for (uint32_t i = 0; i < n_nodes; i++) {
+            if (out.node_kind[i] == 1) off[i] = (ii++) * kSmallInnerBytes;
+            else if (out.node_kind[i] == 2) off[i] = static_cast<uint32_t>(end_off) + 4u + (li++) * leaf_bytes;
+        }
+        auto ref16 = [&](uint32_t r) -> uint32_t { return r == kRefEnd ? static_cast<uint32_t>(end_off) : off[r & kRefIndexMask]; };
+        out.small_bytes = static_cast<uint32_t>(total);
+        out.small_end = static_cast<uint32_t>(end_off);
+        out.small_leaf_links = leaf_bytes - 16u;
+        out.small_nodes.assign((static_cast<size_t>(total) + 15u) / 16u * 4u, 0u);  // the extend kernel copies it in 16-byte pieces
+        for (uint32_t i = 0; i < n_nodes; i++) {
+            if (out.node_kind[i] == 0) continue;
             const uint32_t *w = &out.nodes[static_cast<size_t>(i) * kNodeWords];
-            uint32_t *s = &out.small_nodes[static_cast<size_t>(i) * sw];
-            if (!is_leaf(nodes[i])) {
+            uint32_t *s = &out.small_nodes[off[i] / 4u];
+            if (out.node_kind[i] == 1) {
                 for (int k = 0; k < 3; k++) { s[3 * k] = w[2 * k]; s[3 * k + 1] = w[2 * k + 1]; s[3 * k + 2] = w[2 * k]; }
                 const uint32_t axis = (w[6] >> RRT_NODE_AXIS_SHIFT) & 3u;
-                s[9] = axis * 5u | (ref14(w[7]) << 4) | (ref14(w[6] & (kRefLeafBit | kRefIndexMask)) << (4 + kRef14Bits));
-            } else {
-                for (int k = 0; k < 6; k++) s[k] = w[k];
-                if (moving && (w[5] & 1u)) {
-                    const Float4 &m = out.motion[w[4] & kLeafPrimMask];
-                    s[6] = f2u(m.x); s[7] = f2u(m.y); s[8] = f2u(m.z);
+                const uint32_t left = ref16(w[7]), right = ref16(w[6] & (kRefLeafBit | kRefIndexMask));
+                for (uint32_t o = 0; o < 8; o++) {
+                    const uint32_t near_ref = ((o >> axis) & 1u) ? right : left;  // acceleration.rs:253-267
+                    s[kSmallLinkOffset / 4u + o] = near_ref | (ref16(w[8 + o]) << 16);
                 }
+            } else {
+                for (int k = 0; k < 5; k++) s[k] = w[k];
+                uint32_t *links = s + 5;
+                if (moving) {
+                    s[5] = w[5];
+                    if (w[5] & 1u) {
+                        const Float4 &m = out.motion[w[4] & kLeafPrimMask];
+                        s[6] = f2u(m.x); s[7] = f2u(m.y); s[8] = f2u(m.z);
+                    }
+                    links = s + 9;
+                }
+                for (int o = 0; o < 8; o += 2) links[o / 2] = ref16(w[8 + o]) | (ref16(w[8 + o + 1]) << 16);
             }
-            for (int o = 0; o < 8; o += 2) s[10 + o / 2] = ref14(w[8 + o]) | (ref14(w[8 + o + 1]) << 16);
         }
-        out.small_root = ref14(out.root_ref);
-        out.small_nodes.resize((out.small_nodes.size() + 3u) & ~size_t(3), 0u);  // the extend kernel copies it in 16-byte pieces
+        out.small_root = ref16(out.root_ref);
     }
     return RRT_OK;
 }

@@ -25,13 +25,15 @@ constexpr uint32_t kNodeWords = 16;             // 64 bytes
 constexpr uint32_t kLeafPrimMask = 0x3FFFFFFFu; // leaf word 4: sphere index | material kind << 30
 constexpr uint32_t kLeafKindShift = 30;
 
-// Compact layout for scenes small enough to live in a workgroup's LDS: 56-byte nodes.  A 14-bit reference is the
-// node's offset in 8-byte units with bit 13 set for a leaf.
-constexpr uint32_t kRef14LeafBit = 0x2000u;
-constexpr uint32_t kRef14End = 0x1FFFu;
-constexpr uint32_t kRef14Bits = 14;
-constexpr uint32_t kSmallWords = 14;
-constexpr uint32_t kSmallLdsBudget = 64u * 1024u;
+// Compact layout for scenes small enough to live in a workgroup's LDS.  A 16-bit reference is the node's byte offset
+// in the image (= its LDS address: the image starts at LDS address 0).  Inner nodes (68 bytes) come first, then one
+// unused word whose offset is the reference that means "nothing left to visit", then the leaves (36 bytes, or 52 in a
+// scene with moving spheres); so `ref < end` is an inner node and `ref > end` a leaf.
+constexpr uint32_t kSmallInnerBytes = 68;
+constexpr uint32_t kSmallLeafBytes = 36;        // centre, radius^2, sphere word, 8 exit links of 16 bits
+constexpr uint32_t kSmallLeafBytesMoving = 52;  // + moving flag and centre1 - centre0
+constexpr uint32_t kSmallLinkOffset = 36;       // inner: byte offset of the 8 (near child | exit << 16) words
+constexpr uint32_t kSmallLdsBudget = 0xFFF0u;   // every offset fits 16 bits
 
 // Per-sphere info word: material index | kind << 28 | moving << 31
 constexpr uint32_t kInfoMatMask = 0x0FFFFFFFu;
@@ -54,15 +56,18 @@ struct SceneLayout {
     uint32_t root_ref = kRefEnd;
     uint32_t max_leaf_depth = 0;
 
-    // Compact node words (empty when the scene does not qualify).
+    // Compact image (empty when the scene does not qualify), as words.
     // Inner: [0..8] per axis (min, max, min), so that the two words starting at 3 * axis + s are (near, far) for a ray
-    //        whose direction is negative (s = 1) or not (s = 0) along that axis; [9] 5 * axis | left ref << 4 |
-    //        right ref << 18; [10..13] eight 16-bit exit links.
-    // Leaf:  [0..2] centre at time0, [3] radius^2, [4] sphere index | kind << 30, [5] bit 0 = moving,
-    //        [6..8] centre1 - centre0, [10..13] exit links.
+    //        whose direction is negative (s = 1) or not (s = 0) along that axis; [9..16] for each of the 8 sign octants of
+    //        the ray direction: reference of the child the reference visits first (acceleration.rs:253-267) in the low
+    //        half, exit link in the high half.
+    // Leaf:  [0..2] centre at time0, [3] radius^2, [4] sphere index | kind << 30, then (scenes with moving spheres)
+    //        [5] bit 0 = moving, [6..8] centre1 - centre0, then four words of eight 16-bit exit links.
     std::vector<uint32_t> small_nodes;
-    uint32_t small_words = 0;
-    uint32_t small_root = kRef14End;
+    uint32_t small_bytes = 0;       // size of the image
+    uint32_t small_root = 0;        // reference of the root
+    uint32_t small_end = 0;         // the reference that ends a walk
+    uint32_t small_leaf_links = 0;  // byte offset of the exit links inside a leaf
 
     // Top of the tree (whole levels from the root, at most kTopMaxNodes nodes) in the 64-byte node format, for scenes
     // whose nodes stay in HBM: the extend kernel keeps this copy in LDS.  Filled by make_top_tree.

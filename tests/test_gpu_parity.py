@@ -631,6 +631,28 @@ def test_render_multi_on_two_gpus_over_rccl(gpu_ctx):
         second.close()
 
 
+def test_two_process_render_over_nccl(gpu_ctx):
+    """One process per GPU over torch.distributed's nccl backend (bench.py --gpus 2 on the target render at reduced samples):
+    fresh child processes, tile shards gathered on rank 0.  Skipped where the machine has one GPU."""
+    import json
+    import subprocess
+    import sys
+    try:
+        rrt_amd.Context(1).close()
+    except rrt_amd.RrtError:
+        pytest.skip("one GPU here")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for shard in ("tile", "sample"):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                            "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--spp", "16",
+                            "--shard", shard, "--no-roofline"], capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+        out = json.loads(line)
+        assert out["n_gpus"] == 2 and out["config"]["backend"] == "nccl" and out["config"]["ranks"] == 2
+        assert out["config"]["rays_per_step"] > 3840 * 2160 * 16
+
+
 def test_build_bvh_argument_errors(gpu_ctx):
     import ctypes as C
     sp = np.zeros((3, 9), np.float32); sp[:, 0] = [0, 1, 2]; sp[:, 3] = [0, 1, 2]; sp[:, 8] = 0.3
