@@ -65,13 +65,13 @@ constexpr uint32_t kFlagWords = kMaxParts * 32 * 32;  // per part: 32 flag words
 constexpr uint32_t kChunk = 8;  // extend+shade rounds queued between two looks at the alive flag
 constexpr uint32_t kMaxDepthLimit = 4096;  // depth and trail length share one 32-bit word per path
 // Limits of rrt_render_device_noalloc, which works inside the library's static device array (noalloc.hip): with all three
-// at their maximum the path pool takes 5.8 MB and one sample of radiance plus the sums 7.3 MB of the 16 MiB.
+// at their maximum the path pool takes 5.5 MB and one sample of radiance plus the sums 7.3 MB of the 16 MiB.
 constexpr uint32_t kNoAllocSlots = 16384;
 constexpr uint32_t kNoAllocMaxPixels = 512 * 512;
 constexpr uint32_t kNoAllocMaxDepth = 64;
 
 // The pieces of device memory one render call works in: the path pool, its bookkeeping, the framebuffer planes.
-enum WsPiece { WS_RAYA, WS_RAYB, WS_RAYC, WS_RECENT, WS_RNG, WS_DEPTH, WS_HIT, WS_TRAIL, WS_QUEUE, WS_QCOUNT, WS_WAVE_STATS, WS_CURSORS,
+enum WsPiece { WS_RAYA, WS_RAYB, WS_RECENT, WS_RNG, WS_DEPTH, WS_HIT, WS_TRAIL, WS_QUEUE, WS_QCOUNT, WS_WAVE_STATS, WS_CURSORS,
                WS_FLAGS, WS_STATS_OUT, WS_ACCUM, WS_RAD, WS_PIXEL_MAP, WS_COUNT };
 
 struct RenderPlan {
@@ -81,7 +81,7 @@ struct RenderPlan {
     // fills bytes[] from the sizes above; returns the total with every piece rounded up to 256 bytes
     size_t size_pieces() {
         const size_t sl = slots;
-        bytes[WS_RAYA] = bytes[WS_RAYB] = bytes[WS_RAYC] = bytes[WS_RECENT] = bytes[WS_RNG] = sl * 16;
+        bytes[WS_RAYA] = bytes[WS_RAYB] = bytes[WS_RECENT] = bytes[WS_RNG] = sl * 16;
         bytes[WS_DEPTH] = sl * 4; bytes[WS_HIT] = sl * 8; bytes[WS_TRAIL] = sl * 4 * trail_levels; bytes[WS_QUEUE] = sl * 4;
         bytes[WS_QCOUNT] = (size_t)n_waves * 4; bytes[WS_WAVE_STATS] = (size_t)n_waves * kWaveStatWords * 8;
         bytes[WS_CURSORS] = (size_t)kCursorShards * kCursorStride * 4; bytes[WS_FLAGS] = kFlagWords * 4; bytes[WS_STATS_OUT] = kWaveStatWords * 8;
@@ -437,7 +437,7 @@ int render_queued(rrt_ctx *c, const rrt_render_params &P, const RenderTarget &T,
         }
 
         PathState ps{};
-        ps.rayA = static_cast<float4 *>(at(WS_RAYA)); ps.rayB = static_cast<float4 *>(at(WS_RAYB)); ps.rayC = static_cast<float4 *>(at(WS_RAYC));
+        ps.rayA = static_cast<float4 *>(at(WS_RAYA)); ps.rayB = static_cast<float4 *>(at(WS_RAYB));
         ps.recent = static_cast<uint4 *>(at(WS_RECENT)); ps.rng = static_cast<uint4 *>(at(WS_RNG));
         ps.depth = static_cast<uint32_t *>(at(WS_DEPTH)); ps.hit = static_cast<uint2 *>(at(WS_HIT)); ps.trail = static_cast<uint32_t *>(at(WS_TRAIL));
         ps.queue = static_cast<uint32_t *>(at(WS_QUEUE)); ps.qcount = static_cast<uint32_t *>(at(WS_QCOUNT)); ps.n_slots = slots; ps.trail_levels = pl.trail_levels;
@@ -645,9 +645,9 @@ int rrt_intersect(rrt_ctx *c, uint32_t n, const float *org, const float *dir, co
     pl.slots = (n + kWaveSlots - 1) / kWaveSlots * kWaveSlots;
     pl.n_waves = pl.slots / kWaveSlots;
     pl.size_pieces();
-    for (int i : {WS_RAYA, WS_RAYB, WS_RAYC, WS_HIT, WS_QUEUE, WS_QCOUNT, WS_WAVE_STATS}) HIP_TRY(c->ws[i].ensure(std::max<size_t>(16, pl.bytes[i])));
+    for (int i : {WS_RAYA, WS_RAYB, WS_HIT, WS_QUEUE, WS_QCOUNT, WS_WAVE_STATS}) HIP_TRY(c->ws[i].ensure(std::max<size_t>(16, pl.bytes[i])));
     PathState ps{};
-    ps.rayA = c->ws[WS_RAYA].as<float4>(); ps.rayB = c->ws[WS_RAYB].as<float4>(); ps.rayC = c->ws[WS_RAYC].as<float4>();
+    ps.rayA = c->ws[WS_RAYA].as<float4>(); ps.rayB = c->ws[WS_RAYB].as<float4>();
     ps.hit = c->ws[WS_HIT].as<uint2>(); ps.queue = c->ws[WS_QUEUE].as<uint32_t>(); ps.qcount = c->ws[WS_QCOUNT].as<uint32_t>();
     ps.n_slots = pl.slots; ps.trail_levels = 1; ps.wave_begin = 0; ps.wave_end = pl.n_waves;
     ps.t_min = t_min; ps.t_max = t_max;

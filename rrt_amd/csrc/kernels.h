@@ -49,7 +49,6 @@ struct SceneDev {
 struct PathState {
     float4 *rayA;      // origin xyz, time
     float4 *rayB;      // direction xyz, path id within the batch (as bits)
-    float4 *rayC;      // 1/direction xyz (types.rs:21-23), direction.direction (sphere.rs:71): per-ray constants of the walk
     uint4 *rng;        // Xoshiro128Plus state
     uint32_t *depth;   // scatters so far (low 16 bits) | trail entries written (high 16 bits)
     uint2 *hit;        // extend -> shade: {t bits, sphere index | material kind << 30, or kPrimNone}

@@ -405,7 +405,8 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
             }
             if (take) {
                 slot = n_slot;
-                const float4 nA = P.rayA[n_slot], nB = P.rayB[n_slot], nC = P.rayC[n_slot];
+                const float4 nA = P.rayA[n_slot], nB = P.rayB[n_slot];
+                const float4 nC = ray_constants(mk(nB.x, nB.y, nB.z));  // 1/d and d.d, once per ray (types.rs:21-23, sphere.rs:71)
                 ray_load(r, nA, nB, nC, P.t_min, P.t_max, S, uniform_times);  // lib.rs:57
                 st.prepare(r);
                 cur = st.root();
@@ -544,7 +545,6 @@ DEV bool start_path(const PathState &P, const BatchDev &Bt, const CameraDev &C, 
     generate_path(Bt, C, (uint32_t)p64, A, B, g);
     P.rayA[slot] = A;
     P.rayB[slot] = B;
-    P.rayC[slot] = ray_constants(mk(B.x, B.y, B.z));
     P.rng[slot] = make_uint4(g.s0, g.s1, g.s2, g.s3);
     P.depth[slot] = 0u;
     return true;
@@ -786,7 +786,6 @@ DEV void shade_slot(const SceneDev &S, const Tables &T, const PathState &P, cons
     if (alive) {
         P.rayA[slot] = oA;
         P.rayB[slot] = oB;
-        P.rayC[slot] = ray_constants(mk(oB.x, oB.y, oB.z));  // once for scattered and new rays alike
         P.rng[slot] = make_uint4(g.s0, g.s1, g.s2, g.s3);
         P.depth[slot] = o_depth;
         P.recent[slot] = o_recent;  // also where nothing changed: a store that covers whole lines costs the memory system less than a sparse one
@@ -999,12 +998,21 @@ __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads) void k
 #endif
     // ---- 5. the live-slot list, still in slot order (ballot + prefix popcount) ----
     uint32_t out_count = 0;
+    uint64_t am[4];
 #pragma unroll
     for (uint32_t t = 0; t < 4u; t++) {
         const bool alive = ((alive_bits >> t) & 1u) || (((absorbed_bits >> t) & 1u) && rank[t] < n_refilled);
-        const uint64_t am = __ballot(alive);
-        if (alive) P.queue[base + out_count + (uint32_t)__popcll(am & lt_mask)] = sq[t];
-        out_count += (uint32_t)__popcll(am);
+        am[t] = __ballot(alive);
+        out_count += (uint32_t)__popcll(am[t]);
+    }
+    // a full list is every slot of the wave in order; if it was full and stays full, what is in memory is already right
+    if (!(count == kWaveSlots && out_count == kWaveSlots)) {
+        uint32_t at = 0;
+#pragma unroll
+        for (uint32_t t = 0; t < 4u; t++) {
+            if ((am[t] >> lane) & 1ull) P.queue[base + at + (uint32_t)__popcll(am[t] & lt_mask)] = sq[t];
+            at += (uint32_t)__popcll(am[t]);
+        }
     }
     if (lane == 0) {
         P.qcount[wave] = out_count;
@@ -1068,7 +1076,6 @@ __global__ void k_intersect_setup(PathState P, uint32_t n, const float *org, con
     const V3 d = mk(dir[i * 3u], dir[i * 3u + 1u], dir[i * 3u + 2u]);
     P.rayA[i] = make_float4(org[i * 3u], org[i * 3u + 1u], org[i * 3u + 2u], time ? time[i] : 0.0f);
     P.rayB[i] = make_float4(d.x, d.y, d.z, 0.0f);
-    P.rayC[i] = ray_constants(d);
     P.queue[i] = i;
     if ((i & (kWaveSlots - 1u)) == 0u) P.qcount[i / kWaveSlots] = min(kWaveSlots, n - i);
 }
