@@ -443,6 +443,7 @@ int render_queued(rrt_ctx *c, const rrt_render_params &P, const RenderTarget &T,
         ps.queue = static_cast<uint32_t *>(at(WS_QUEUE)); ps.qcount = static_cast<uint32_t *>(at(WS_QCOUNT)); ps.n_slots = slots; ps.trail_levels = pl.trail_levels;
         ps.wave_begin = 0; ps.wave_end = n_waves;
         ps.t_min = 0.001f; ps.t_max = std::numeric_limits<float>::max();  // lib.rs:57
+        ps.layout = (c->moving ? kLayoutTimed : 0u) | (c->n_spheres <= kShadeTableSpheres && P.max_depth <= kNarrowMaxDepth ? kLayoutNarrow : 0u);
         uint64_t *wstats = static_cast<uint64_t *>(at(WS_WAVE_STATS));
         HIP_TRY(hipMemsetAsync(wstats, 0, (size_t)n_waves * kWaveStatWords * 8, s));
         uint32_t *flags = static_cast<uint32_t *>(at(WS_FLAGS));
@@ -651,6 +652,7 @@ int rrt_intersect(rrt_ctx *c, uint32_t n, const float *org, const float *dir, co
     ps.hit = c->ws[WS_HIT].as<uint2>(); ps.queue = c->ws[WS_QUEUE].as<uint32_t>(); ps.qcount = c->ws[WS_QCOUNT].as<uint32_t>();
     ps.n_slots = pl.slots; ps.trail_levels = 1; ps.wave_begin = 0; ps.wave_end = pl.n_waves;
     ps.t_min = t_min; ps.t_max = t_max;
+    ps.layout = c->moving ? kLayoutTimed : 0u;
     launch_intersect_setup(s, ps, n, c->q_org.as<float>(), c->q_dir.as<float>(), time ? c->q_time.as<float>() : nullptr);
     launch_extend(s, c->sd, ps, c->moving, false, 32u, 16u, c->ws[WS_WAVE_STATS].as<uint64_t>());
     launch_intersect_gather(s, ps, n, c->q_t.as<float>(), c->q_obj.as<uint32_t>());

@@ -46,8 +46,17 @@ struct SceneDev {
 
 // All per-path state lives in planes indexed by slot.  A wave owns slots [wave*kWaveSlots, +kWaveSlots)
 // and the matching stretch of `queue`, which lists its live slots; `qcount[wave]` is the list length.
+// PathState::layout bits.  kLayoutTimed: the origin plane carries the ray's time in a fourth word (scenes with moving
+// spheres; elsewhere nothing reads the time and the plane is packed, 12 bytes per slot).  kLayoutNarrow: depth, trail
+// length and the four newest trail entries share one 8-byte record per slot in the `recent` plane (8 bits each for the
+// counts, 10 bits per entry: scenes of at most 1024 spheres rendered with a depth limit of at most 255); otherwise a
+// 4-byte `depth` plane and 16 bytes per slot in `recent`.
+constexpr uint32_t kLayoutTimed = 1u, kLayoutNarrow = 2u;
+constexpr uint32_t kNarrowMaxDepth = 255;
+constexpr uint32_t kShadeTableSpheres = 512;  // scenes up to this size: the shade kernel keeps the sphere tables in LDS and the path state narrow
+
 struct PathState {
-    float4 *rayA;      // origin xyz, time
+    float4 *rayA;      // origin xyz, time (kLayoutTimed) or origin xyz packed
     float4 *rayB;      // direction xyz, path id within the batch (as bits)
     uint4 *rng;        // Xoshiro128Plus state
     uint32_t *depth;   // scatters so far (low 16 bits) | trail entries written (high 16 bits)
@@ -60,6 +69,7 @@ struct PathState {
     uint32_t trail_levels;  // levels per path in `trail` (the depth limit)
     uint32_t wave_begin, wave_end;  // the waves (slot stretches) one launch works on
     float t_min, t_max;             // the interval Bvh::hit searches: 0.001 and f32::MAX for a render (lib.rs:57)
+    uint32_t layout;                // kLayout* bits
 };
 
 // Division of a 32-bit number by an invariant divisor with one multiply-high (Granlund & Montgomery): for every n,

@@ -125,6 +125,42 @@ DEV void generate_path(const BatchDev &Bt, const CameraDev &C, uint32_t p, float
     B = make_float4(dir.x, dir.y, dir.z, u2f(p));
 }
 
+// ---- the two layouts of the origin plane and of the depth / trail-window state (kernels.h: kLayout*) ----
+struct F3 { float x, y, z; };
+DEV float4 origin_load(const PathState &P, uint32_t slot, bool timed) {
+    if (timed) return P.rayA[slot];
+    const F3 v = reinterpret_cast<const F3 *>(P.rayA)[slot];
+    return make_float4(v.x, v.y, v.z, 0.0f);
+}
+DEV void origin_store(const PathState &P, uint32_t slot, bool timed, float4 A) {
+    if (timed) P.rayA[slot] = A;
+    else { F3 v; v.x = A.x; v.y = A.y; v.z = A.z; reinterpret_cast<F3 *>(P.rayA)[slot] = v; }
+}
+// depth word: scatters so far (low 16 bits) | trail entries written (high 16 bits)
+DEV uint32_t narrow_depth_word(uint32_t x) { return (x & 0xFFu) | ((x & 0xFF00u) << 8); }
+DEV uint32_t depth_load(const PathState &P, uint32_t slot, bool narrow) {
+    return narrow ? narrow_depth_word(reinterpret_cast<const uint2 *>(P.recent)[slot].x) : P.depth[slot];
+}
+DEV void meta_load(const PathState &P, uint32_t slot, bool narrow, uint32_t &depth_word, uint4 &recent) {
+    if (narrow) {
+        const uint2 m = reinterpret_cast<const uint2 *>(P.recent)[slot];
+        depth_word = narrow_depth_word(m.x);
+        recent = make_uint4((m.x >> 16) & 0x3FFu, m.y & 0x3FFu, (m.y >> 10) & 0x3FFu, (m.y >> 20) & 0x3FFu);
+    } else {
+        depth_word = P.depth[slot];
+        recent = P.recent[slot];
+    }
+}
+DEV void meta_store(const PathState &P, uint32_t slot, bool narrow, uint32_t depth_word, uint4 recent) {
+    if (narrow) {
+        reinterpret_cast<uint2 *>(P.recent)[slot] = make_uint2((depth_word & 0xFFu) | ((depth_word >> 8) & 0xFF00u) | (recent.x << 16),
+                                                               recent.y | (recent.z << 10) | (recent.w << 20));
+    } else {
+        P.depth[slot] = depth_word;
+        P.recent[slot] = recent;
+    }
+}
+
 // ---- BVH traversal (acceleration.rs:221-272) over the linked layouts of scene_layout.h ----
 //
 // A node store hands out the words of a node; two exist: the 64-byte nodes in HBM (any scene) and the compact copy in
@@ -405,7 +441,7 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
             }
             if (take) {
                 slot = n_slot;
-                const float4 nA = P.rayA[n_slot], nB = P.rayB[n_slot];
+                const float4 nA = origin_load(P, n_slot, MOVING), nB = P.rayB[n_slot];  // MOVING scenes keep the time in the origin plane
                 const float4 nC = ray_constants(mk(nB.x, nB.y, nB.z));  // 1/d and d.d, once per ray (types.rs:21-23, sphere.rs:71)
                 ray_load(r, nA, nB, nC, P.t_min, P.t_max, S, uniform_times);  // lib.rs:57
                 st.prepare(r);
@@ -537,16 +573,17 @@ DEV float reflectance(float cosine, float r0) { return r0 + (1.0f - r0) * pow5(1
 // from shard wave % n_shards.  `n` is the wave's running count of claims from its shard.
 DEV uint64_t path_of_claim(const BatchDev &Bt, uint32_t shard, uint32_t n) { return ((uint64_t)(n >> 6) * Bt.n_shards + shard) * 64ull + (n & 63u); }
 
-DEV bool start_path(const PathState &P, const BatchDev &Bt, const CameraDev &C, uint32_t shard, uint32_t n, uint32_t slot) {
+DEV bool start_path(const PathState &P, const BatchDev &Bt, const CameraDev &C, uint32_t shard, uint32_t n, uint32_t slot, bool timed, bool narrow) {
     const uint64_t p64 = path_of_claim(Bt, shard, n);
     if (p64 >= (uint64_t)Bt.n_paths) return false;
     float4 A, B;
     Rng g;
     generate_path(Bt, C, (uint32_t)p64, A, B, g);
-    P.rayA[slot] = A;
+    origin_store(P, slot, timed, A);
     P.rayB[slot] = B;
     P.rng[slot] = make_uint4(g.s0, g.s1, g.s2, g.s3);
-    P.depth[slot] = 0u;
+    if (narrow) reinterpret_cast<uint2 *>(P.recent)[slot] = make_uint2(0u, 0u);
+    else P.depth[slot] = 0u;
     return true;
 }
 
@@ -567,7 +604,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_raygen(PathState P, BatchDev 
     uint32_t out_count = 0;
     for (uint32_t t0 = 0; t0 < kWaveSlots; t0 += 64u) {
         const uint32_t slot = base + t0 + lane;
-        const bool alive = start_path(P, Bt, C, shard, base_n + t0 + lane, slot);
+        const bool alive = start_path(P, Bt, C, shard, base_n + t0 + lane, slot, (P.layout & kLayoutTimed) != 0u, (P.layout & kLayoutNarrow) != 0u);
         const uint64_t am = __ballot(alive);
         if (alive) P.queue[base + out_count + (uint32_t)__popcll(am & ((1ull << lane) - 1ull))] = slot;
         out_count += (uint32_t)__popcll(am);
@@ -608,7 +645,7 @@ static_assert(RRT_MAT_LAMBERTIAN == CL_LAMB && RRT_MAT_METAL == CL_METAL && RRT_
 // LDS words per wave: one 16-byte entry per list position
 constexpr uint32_t kShadeLdsWords = kWaveSlots * 4u;
 constexpr uint32_t kShadeTableThreads = 512;   // block size of the variant that keeps the per-sphere tables in LDS
-constexpr uint32_t kShadeTableSpheres = 512;   // and the largest scene it takes: 2 x 16 bytes per sphere
+static_assert(kShadeTableSpheres <= 1024, "the narrow trail entries have 10 bits");  // kernels.h: the largest scene the table variant takes, 2 x 16 bytes per sphere
 
 // What step 3 reads of one path slot
 struct SlotIn {
@@ -620,9 +657,9 @@ struct SlotIn {
 };
 // `hit_word` is the sphere word of the slot's hit record as step 1 saw it, or kPrimNone: with it the table rows can be
 // asked for at once, a tile ahead, instead of by a dependent gather in the middle of the tile.
-template <bool PREFETCH_ROWS>
+template <bool PREFETCH_ROWS, bool TIMED, bool NARROW>
 DEV void load_slot(const SceneDev &S, const PathState &P, bool active, uint32_t slot, uint32_t hit_word, SlotIn &in) {
-    if (active) { in.A = P.rayA[slot]; in.B = P.rayB[slot]; in.h = P.hit[slot]; in.depth = P.depth[slot]; in.recent = P.recent[slot]; }
+    if (active) { in.A = origin_load(P, slot, TIMED); in.B = P.rayB[slot]; in.h = P.hit[slot]; meta_load(P, slot, NARROW, in.depth, in.recent); }
     if (PREFETCH_ROWS && active && hit_word != kPrimNone) { in.sph = S.sph[hit_word & kLeafPrimMask]; in.mat = S.prim_att[hit_word & kLeafPrimMask]; }
 }
 
@@ -647,7 +684,7 @@ struct NewPath { float4 A, B; uint4 rng; bool ok; };
 // Step 3 for one lane.  `gw` is the slot's LDS entry: the generator state (before the accepted draw, for Lambertian and
 // metal).  `np` is the path that takes over the slot if this one ends here.
 template <bool MOVING, class Tables>
-DEV void shade_slot(const SceneDev &S, const Tables &T, const PathState &P, const BatchDev &Bt, uint32_t cls, uint32_t slot,
+DEV void shade_slot(const SceneDev &S, const Tables &T, const PathState &P, const BatchDev &Bt, uint32_t cls, uint32_t slot,  // Tables::kInLds: the narrow state layout
                     const SlotIn &in, uint4 gw, const NewPath &np, bool &alive, bool &absorbed, bool &started) {
     const float4 A = in.A, B = in.B;
     const uint32_t depth = in.depth & 0xFFFFu;       // scatters so far
@@ -784,11 +821,10 @@ DEV void shade_slot(const SceneDev &S, const Tables &T, const PathState &P, cons
         started = true;
     }
     if (alive) {
-        P.rayA[slot] = oA;
+        origin_store(P, slot, MOVING, oA);
         P.rayB[slot] = oB;
         P.rng[slot] = make_uint4(g.s0, g.s1, g.s2, g.s3);
-        P.depth[slot] = o_depth;
-        P.recent[slot] = o_recent;  // also where nothing changed: a store that covers whole lines costs the memory system less than a sparse one
+        meta_store(P, slot, Tables::kInLds, o_depth, o_recent);  // also where nothing changed: a store that covers whole lines costs the memory system less than a sparse one
     }
 }
 
@@ -857,11 +893,11 @@ __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads) void k
             for (uint32_t t = 0; t < 4u; t++) sq[t] = lane + 64u * t < count ? P.queue[base + lane + 64u * t] : 0u;
         }
         // the first tile's ray and trail window travel together with everything the classification needs
-        if (lane < count) { buf[0].A = P.rayA[sq[0]]; buf[0].B = P.rayB[sq[0]]; buf[0].recent = P.recent[sq[0]]; }
+        if (lane < count) { buf[0].A = origin_load(P, sq[0], MOVING); buf[0].B = P.rayB[sq[0]]; meta_load(P, sq[0], TABLES, buf[0].depth, buf[0].recent); }
 #pragma unroll
         for (uint32_t t = 0; t < 4u; t++) {
             h[t] = make_uint2(0u, 0u); dep[t] = 0u; rg[t] = make_uint4(0u, 0u, 0u, 0u);
-            if (lane + 64u * t < count) { h[t] = P.hit[sq[t]]; dep[t] = P.depth[sq[t]]; rg[t] = P.rng[sq[t]]; }
+            if (lane + 64u * t < count) { h[t] = P.hit[sq[t]]; dep[t] = depth_load(P, sq[t], TABLES); rg[t] = P.rng[sq[t]]; }
         }
 #pragma unroll
         for (uint32_t t = 0; t < 4u; t++) {
@@ -929,7 +965,7 @@ __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads) void k
 #pragma unroll
     for (uint32_t t = 0; t < 4u; t++) {
         if (t < n_tiles) {
-            if (t + 1u < 4u) load_slot<!TABLES>(S, P, lane + 64u * (t + 1u) < count, sq[(t + 1u) & 3u], hw[(t + 1u) & 3u], buf[(t + 1u) & 1u]);
+            if (t + 1u < 4u) load_slot<!TABLES, MOVING, TABLES>(S, P, lane + 64u * (t + 1u) < count, sq[(t + 1u) & 3u], hw[(t + 1u) & 3u], buf[(t + 1u) & 1u]);
             const uint32_t pos = lane + 64u * t;
             const uint32_t cls = (classes >> (4u * t)) & 15u;
             bool alive = false, absorbed = false, started = false;
@@ -988,7 +1024,7 @@ __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads) void k
         for (uint32_t i0 = 0; i0 < n_need; i0 += 64u) {
             const uint32_t i = i0 + lane;
             bool started = false;
-            if (i < n_need) started = start_path(P, Bt, C, shard, n + i, l_slot[i]);
+            if (i < n_need) started = start_path(P, Bt, C, shard, n + i, l_slot[i], MOVING, TABLES);
             n_refilled += (uint32_t)__popcll(__ballot(started));  // path ids grow with i: the paths that still exist are a prefix of the list
         }
     }
@@ -1074,7 +1110,7 @@ __global__ void k_intersect_setup(PathState P, uint32_t n, const float *org, con
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const V3 d = mk(dir[i * 3u], dir[i * 3u + 1u], dir[i * 3u + 2u]);
-    P.rayA[i] = make_float4(org[i * 3u], org[i * 3u + 1u], org[i * 3u + 2u], time ? time[i] : 0.0f);
+    origin_store(P, i, (P.layout & kLayoutTimed) != 0u, make_float4(org[i * 3u], org[i * 3u + 1u], org[i * 3u + 2u], time ? time[i] : 0.0f));
     P.rayB[i] = make_float4(d.x, d.y, d.z, 0.0f);
     P.queue[i] = i;
     if ((i & (kWaveSlots - 1u)) == 0u) P.qcount[i / kWaveSlots] = min(kWaveSlots, n - i);
@@ -1164,7 +1200,7 @@ void launch_extend(hipStream_t s, const SceneDev &S, const PathState &P, bool mo
 void launch_shade(hipStream_t s, const SceneDev &S, const PathState &P, const BatchDev &B, const CameraDev &C, bool moving,
                   bool count, uint64_t *wave_stats) {
     const uint32_t n_waves = P.wave_end - P.wave_begin;
-    if (S.n_spheres <= kShadeTableSpheres) {
+    if (P.layout & kLayoutNarrow) {  // set by the host for scenes of at most kShadeTableSpheres spheres (and a depth limit the narrow state holds)
         const uint32_t wpb = kShadeTableThreads / 64u;
         const dim3 g((n_waves + wpb - 1u) / wpb), b(kShadeTableThreads);
         const size_t lds = (size_t)wpb * kShadeLdsWords * 4u + (size_t)S.n_spheres * 32u;
