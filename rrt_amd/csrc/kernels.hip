@@ -47,8 +47,21 @@ DEV float sqrt_rn(float x) {
     return r;
 }
 
+// Correctly rounded 1 / x in 3 instructions instead of the 11 of an IEEE division: the hardware estimate and one
+// Newton step.  Checked against 1.0f / x on every one of the 2^32 inputs (tools/micro/recip_exact.hip): the result
+// is the same bit for bit unless it comes out NaN (x zero, denormal or infinite) or x is 2^126 or more, where the quotient
+// is denormal.  Both cases show in the result (NaN, or magnitude below 2^-125): if any lane of the wave has one, the whole
+// wave divides.
+DEV bool recip_suspect(float q) { return !(fabsf(q) >= 0x1p-125f); }
+DEV float recip_newton(float x) { const float r0 = __builtin_amdgcn_rcpf(x); return __builtin_fmaf(__builtin_fmaf(-x, r0, 1.0f), r0, r0); }
+DEV float recip_rn(float x) {
+    float q = recip_newton(x);
+    if (__builtin_expect(__ballot(recip_suspect(q)) != 0ull, 0)) q = 1.0f / x;
+    return q;
+}
+
 // ultraviolet normalized(): reciprocal of the magnitude, then one multiply per lane
-DEV V3 normalized(V3 a) { const float r = 1.0f / sqrt_rn(dot3(a, a)); return mk(a.x * r, a.y * r, a.z * r); }
+DEV V3 normalized(V3 a) { const float r = recip_rn(sqrt_rn(dot3(a, a))); return mk(a.x * r, a.y * r, a.z * r); }
 // the multiply half of normalized(): a * (1 / |a|), each component times the reciprocal
 DEV V3 scale_r(V3 a, float r) { return mk(a.x * r, a.y * r, a.z * r); }
 // ultraviolet reflected(): self - (2 * self.dot(n)) * n
@@ -91,7 +104,11 @@ DEV void seed_from_u64(Rng &g, uint64_t seed) {
 }
 
 // Per-ray constants of the walk, computed once where the ray is made: 1/d (types.rs:21-23) and d.d (sphere.rs:71)
-DEV float4 ray_constants(V3 d) { return make_float4(1.0f / d.x, 1.0f / d.y, 1.0f / d.z, dot3(d, d)); }
+DEV float4 ray_constants(V3 d) {
+    float ix = recip_newton(d.x), iy = recip_newton(d.y), iz = recip_newton(d.z);
+    if (__builtin_expect(__ballot(recip_suspect(ix) || recip_suspect(iy) || recip_suspect(iz)) != 0ull, 0)) { ix = 1.0f / d.x; iy = 1.0f / d.y; iz = 1.0f / d.z; }
+    return make_float4(ix, iy, iz, dot3(d, d));
+}
 
 // ---- path generation (lib.rs:93-101, camera.rs:56-66) ----
 DEV uint32_t fd_div(uint32_t n, const FastDiv &f) { const uint32_t t = __umulhi(f.magic, n); return (t + ((n - t) >> f.sh1)) >> f.sh2; }
@@ -702,7 +719,7 @@ DEV void shade_slot(const SceneDev &S, const Tables &T, const PathState &P, cons
     bool ended = false;
     // 1 / |d|, shared by everything that needs the unit direction: the sky (lib.rs:67), metal (materials.rs:47) and glass (materials.rs:83)
     float inv_len = 0.0f;
-    if (cls == CL_METAL || cls == CL_DIEL || cls == CL_SKY) inv_len = 1.0f / sqrt_rn(dot3(d, d));
+    if (cls == CL_METAL || cls == CL_DIEL || cls == CL_SKY) inv_len = recip_rn(sqrt_rn(dot3(d, d)));
     if (cls == CL_SKY) {
         // sky (lib.rs:66-70), then the product of attenuations innermost first (lib.rs:62).  The spheres scattered off
         // on the way are read back from the trail, eight levels per round so that a long path costs few memory round
