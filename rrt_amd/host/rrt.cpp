@@ -6,6 +6,8 @@
 #include <hip/hip_runtime_api.h>
 
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 
 #include <algorithm>
