@@ -87,7 +87,7 @@ def cpu_baseline(ns_sample=200, ns_one_core=8):
     t0 = time.perf_counter()
     _, _, ctr1 = osc.render(NX, NY, ns_one_core, seed=SEED, mode=MODE_REF_POOL, threads=1, state=state, pow5_mode=1)
     dt1 = time.perf_counter() - t0
-    ns_sample = max(8, min(ns_sample, 12 * threads))  # about 20 s whatever the core count
+    ns_sample = max(8, min(NS, 30 * threads))  # 15-25 s whatever the core count
     t0 = time.perf_counter()
     _, _, ctr = osc.render(NX, NY, ns_sample, seed=SEED, mode=MODE_REF_POOL, threads=threads, state=state, pow5_mode=1)
     dt = time.perf_counter() - t0
@@ -299,11 +299,12 @@ def main():
                     step_s = elapsed / args.steps
                     rays_rank0 = cst["rays"]
                     roofline["whole_step_hbm"] = {
-                        "bytes_per_ray": bpr, "algorithmic_bytes_per_ray": round(job_bytes(cst, nx * ny) / cst["rays"], 1),
+                        "bytes_per_ray": bpr, "algorithmic_bytes_per_ray": round((job_bytes(cst, nx * ny) - 32 * cst["inner_visits"] - 36 * cst["leaf_tests"]) / cst["rays"], 1),
                         "achieved": round(bpr["total"] * rays_rank0 / step_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(bpr["total"] * rays_rank0 / step_s / 1e9 / HBM_PEAK_GBS, 4),
                         "note": "measured HBM bytes per ray of extend + shade (FETCH_SIZE x 2 + WRITE_SIZE, separate PMC passes) x this "
-                                "run's rays / this run's step time"}
+                                "run's rays / this run's step time; algorithmic = 120 B of queue payload per ray + 16 B per shaded hit + "
+                                "15 B per pixel (the BVH is walked in LDS)"}
 
     extra = None
     if rank == 0 and world == 1 and not big and not args.no_other_configs:
