@@ -58,8 +58,13 @@ oracle:
 asm: rrt_amd/csrc/kernels.hip | $(OBJDIR)
 	$(HIPCC) $(CXXFLAGS) $(DEVFLAGS) -S --cuda-device-only -Rpass-analysis=kernel-resource-usage $< -o $(OBJDIR)/kernels.s
 
+# the library with per-wave busy-time counters in extend and shade (tools/wave_timing.sh); not part of `all`
+wave-timing: $(LIB)
+	$(HIPCC) $(CXXFLAGS) $(DEVFLAGS) -DRRT_WAVE_TIMING -c rrt_amd/csrc/kernels.hip -o $(OBJDIR)/kernels_wave_timing.o
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o rrt_amd/variant_wavetiming.so $(OBJDIR)/kernels_wave_timing.o $(filter-out $(OBJDIR)/kernels.o,$(OBJS)) -ldl -lpthread
+
 clean:
 	rm -rf $(OBJDIR) $(LIB)
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle asm clean
+.PHONY: all oracle asm wave-timing clean

@@ -535,6 +535,9 @@ template <bool MOVING, bool COUNT>
 __global__ __launch_bounds__(kLdsBlockThreads, 8) void k_extend_lds(SceneDev S, PathState P, uint32_t retire_min, uint32_t leaf_min,
                                                                   uint64_t *wave_stats) {
     extern __shared__ uint4 lds4[];
+#ifdef RRT_WAVE_TIMING
+    const uint64_t wt0 = wall_clock64();
+#endif
     const uint32_t n_vec = (S.small_bytes + 15u) / 16u;  // 16-byte pieces; the host pads the image to a whole number of them
     // next position of the workgroup's ray pool; sum of the workgroup's list lengths.  Behind the nodes, so that the nodes
     // start at LDS address 0 and a node reference needs no base added
@@ -553,8 +556,18 @@ __global__ __launch_bounds__(kLdsBlockThreads, 8) void k_extend_lds(SceneDev S, 
     const uint32_t total = rfl(pool[1]);  // the same for every lane: say so, and the list bookkeeping stays in scalar registers
     const bool pooled = total == n_lists * kWaveSlots;
     const LdsStore<MOVING> st(S.small_root, S.small_end);  // the image starts at LDS address 0: a reference is an LDS address
+#ifdef RRT_WAVE_TIMING
+    const uint64_t wt1 = wall_clock64();
+#endif
     extend_wave<LdsStore<MOVING>, MOVING, COUNT>(st, S, P, wave, lane, retire_min, leaf_min, wave_stats, own_count, pooled ? &pool[0] : nullptr,
                                                  wave0 * kWaveSlots, total);
+#ifdef RRT_WAVE_TIMING
+    {   // time from the end of this wave's work to the end of the workgroup's: the wave's slot stays taken that long
+        const uint64_t wt2 = wall_clock64();
+        __syncthreads();
+        if (lane == 0) { uint64_t *w = wave_stats + (size_t)wave * kWaveStatWords; w[10] += wt2 - wt0; w[11] += wt1 - wt0; w[12] += 1; w[15] += wall_clock64() - wt2; }
+    }
+#endif
 }
 
 // Scenes whose nodes stay in HBM: the top levels of the tree (every ray starts there) are walked in an LDS copy.
@@ -861,6 +874,9 @@ __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads) void k
                                                                                       uint64_t *wave_stats) {
     constexpr uint32_t kThreads = TABLES ? kShadeTableThreads : kBlockThreads;
     extern __shared__ uint4 lds4[];  // per wave kShadeLdsWords words, then (TABLES) the sphere and material tables
+#ifdef RRT_WAVE_TIMING
+    const uint64_t wt0 = wall_clock64();
+#endif
     using Tables = typename std::conditional<TABLES, LdsTables, GlobalTables>::type;
     Tables T;
     if (TABLES) {
@@ -1067,6 +1083,9 @@ __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads) void k
             at += (uint32_t)__popcll(am[t]);
         }
     }
+#ifdef RRT_WAVE_TIMING
+    if (lane == 0) { uint64_t *w = wave_stats + (size_t)wave * kWaveStatWords; w[13] += wall_clock64() - wt0; w[14] += 1; }
+#endif
     if (lane == 0) {
         P.qcount[wave] = out_count;
         if (out_count && Bt.alive_flag) Bt.alive_flag[(wave & 31u) * 32u] = 1u;  // 32 lines share the traffic
