@@ -1,12 +1,16 @@
 // Bvh::build (src/acceleration.rs:131-217) on the GPU: the same tree, node for node and bit for bit, as the recursive
-// host builder (rrt_amd/host/rrt.cpp: Bvh::build_r), built level by level.
+// host builder (rrt_amd/host/rrt.cpp: Bvh::build_r), built level by level.  That is the reference's tree wherever its
+// result is determined; where it leaves the order of tied keys to the library (select_nth_unstable_by in the
+// equal-count split), ties fall as a stable sort puts them.
 //
 // What makes a level-synchronous build possible without knowing the tree in advance:
 //   * a subtree over n objects has exactly 2n-1 nodes and the reference pushes a node before its left subtree and the
 //     left subtree before the right one (:158,198), so the children of node i over (n_left, n_right) objects are nodes
 //     i + 1 and i + 2 * n_left;
-//   * the Middle split (:174-179) is a stable partition of a contiguous range by `centroid[axis] < midpoint`, which a
-//     prefix sum over the whole object array does for every open range of a level at once;
+//   * the Middle split (:174-179) partitions a contiguous range by `centroid[axis] < midpoint`.  The reference's
+//     partition swaps from both ends and is not stable, but which objects land on each side, and with them every box
+//     and every later split, does not depend on their order inside the side; here a stable partition by one prefix sum
+//     over the whole object array serves every open range of a level at once;
 //   * box and centroid bounds of a range are min/max reductions, exact in any order.
 // A range whose Middle split leaves one side empty switches, with its whole subtree, to the equal-count split
 // (:180-193).  Those subtrees (identical centroids: rare and small) are finished on the host by the same rule.
