@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from typing import Optional, Tuple
 
 import numpy as np
@@ -89,6 +90,13 @@ def lib() -> C.CDLL:
         return _lib
     if not os.path.exists(LIB_PATH):
         raise RrtError(f"{LIB_PATH} is missing: build it with `make` (there is no CPU fallback)")
+    # A process that also uses PyTorch has to load torch's HIP runtime before this library's: loaded second, torch finds
+    # no GPU.  The helpers that hand device buffers around (multi.py, bench.py) use torch anyway.
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(LIB_PATH)
     vp, u32, u64, i32, f32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_float
     pf, pu = C.POINTER(C.c_float), C.POINTER(C.c_uint32)

@@ -688,9 +688,16 @@ struct SlotIn {
 // `hit_word` is the sphere word of the slot's hit record as step 1 saw it, or kPrimNone: with it the table rows can be
 // asked for at once, a tile ahead, instead of by a dependent gather in the middle of the tile.
 template <bool PREFETCH_ROWS, bool TIMED, bool NARROW>
-DEV void load_slot(const SceneDev &S, const PathState &P, bool active, uint32_t slot, uint32_t hit_word, SlotIn &in) {
-    if (active) { in.A = origin_load(P, slot, TIMED); in.B = P.rayB[slot]; in.h = P.hit[slot]; meta_load(P, slot, NARROW, in.depth, in.recent); }
-    if (PREFETCH_ROWS && active && hit_word != kPrimNone) { in.sph = S.sph[hit_word & kLeafPrimMask]; in.mat = S.prim_att[hit_word & kLeafPrimMask]; }
+DEV void load_slot(const SceneDev &S, const PathState &P, uint32_t slot, uint32_t hit_word, SlotIn &in) {
+    // Every lane loads, whether its list position is taken or not (`slot` is always a slot of this wave, a miss reads
+    // row 0): a load under a branch makes the compiler wait for everything in flight where the branch joins, and these
+    // loads are meant to stay in flight while the tile before them is shaded.
+    __asm__ volatile("" : "+v"(slot));  // addresses are worked out here, from the slot number, not kept in registers since the classification
+    in.A = origin_load(P, slot, TIMED); in.B = P.rayB[slot]; in.h = P.hit[slot]; meta_load(P, slot, NARROW, in.depth, in.recent);
+    if (PREFETCH_ROWS) {
+        const uint32_t row = hit_word != kPrimNone ? hit_word & kLeafPrimMask : 0u;
+        in.sph = S.sph[row]; in.mat = S.prim_att[row];
+    }
 }
 
 // Where shade reads the per-sphere tables from: HBM through the caches, or (small scenes) a copy in the block's LDS.  An
@@ -870,7 +877,7 @@ DEV NewPath fetch_path(const NewPath &g, int src) {
 }
 
 template <bool MOVING, bool COUNT, bool TABLES>
-__global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads) void k_shade(SceneDev S, PathState P, BatchDev Bt, CameraDev C,
+__global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads, TABLES ? 4 : 3) void k_shade(SceneDev S, PathState P, BatchDev Bt, CameraDev C,
                                                                                       uint64_t *wave_stats) {
     constexpr uint32_t kThreads = TABLES ? kShadeTableThreads : kBlockThreads;
     extern __shared__ uint4 lds4[];  // per wave kShadeLdsWords words, then (TABLES) the sphere and material tables
@@ -918,20 +925,29 @@ __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads) void k
     {
         uint2 h[4];
         uint32_t dep[4];
-        uint4 rg[4];
 #pragma unroll
         for (uint32_t t = 0; t < 4u; t++) sq[t] = base + lane + 64u * t;  // a full list is every slot of the wave, in order
         if (count != kWaveSlots) {
+            // entries past the end of the list are stale: their lanes keep the slot of their own position, which is one
+            // of this wave's, so that every load below can go out whether the position is taken or not
+            uint32_t q[4];
 #pragma unroll
-            for (uint32_t t = 0; t < 4u; t++) sq[t] = lane + 64u * t < count ? P.queue[base + lane + 64u * t] : 0u;
-        }
-        // the first tile's ray and trail window travel together with everything the classification needs
-        if (lane < count) { buf[0].A = origin_load(P, sq[0], MOVING); buf[0].B = P.rayB[sq[0]]; meta_load(P, sq[0], TABLES, buf[0].depth, buf[0].recent); }
+            for (uint32_t t = 0; t < 4u; t++) q[t] = P.queue[base + lane + 64u * t];
 #pragma unroll
-        for (uint32_t t = 0; t < 4u; t++) {
-            h[t] = make_uint2(0u, 0u); dep[t] = 0u; rg[t] = make_uint4(0u, 0u, 0u, 0u);
-            if (lane + 64u * t < count) { h[t] = P.hit[sq[t]]; dep[t] = depth_load(P, sq[t], TABLES); rg[t] = P.rng[sq[t]]; }
+            for (uint32_t t = 0; t < 4u; t++) sq[t] = lane + 64u * t < count ? q[t] : sq[t];
         }
+        // the first tile's ray and trail window travel together with everything the classification needs: all of it
+        // is asked for back to back, with no branch in between (see load_slot), and costs one memory round trip
+        // The generator states go from memory straight into the wave's LDS entries (lane i of column t lands in entry
+        // 64 t + i), through no registers.
+#pragma unroll
+        for (uint32_t t = 0; t < 4u; t++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(P.rng + sq[t]),
+                                             (__attribute__((address_space(3))) void *)(l_ent + 64u * t), 16, 0, 0);
+        buf[0].A = origin_load(P, sq[0], MOVING); buf[0].B = P.rayB[sq[0]]; meta_load(P, sq[0], TABLES, buf[0].depth, buf[0].recent);
+#pragma unroll
+        for (uint32_t t = 0; t < 4u; t++) { h[t] = P.hit[sq[t]]; dep[t] = depth_load(P, sq[t], TABLES); }
+        __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the entries have landed
 #pragma unroll
         for (uint32_t t = 0; t < 4u; t++) {
             uint32_t c;
@@ -941,7 +957,6 @@ __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads) void k
             else c = h[t].y >> kLeafKindShift;
             classes |= c << (4u * t);
             if (!TABLES && c <= CL_DIEL) hw[t] = h[t].y;
-            if (c <= CL_DIEL) l_ent[lane + 64u * t] = rg[t];
             end_before[t] = n_ending;
             n_ending += (uint32_t)__popcll(__ballot(c == CL_SKY || c == CL_CUT));
             if (COUNT) {
@@ -950,7 +965,7 @@ __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads) void k
             }
         }
         buf[0].h = h[0]; buf[0].depth = dep[0];
-        if (!TABLES && hw[0] != kPrimNone) { buf[0].sph = S.sph[hw[0] & kLeafPrimMask]; buf[0].mat = S.prim_att[hw[0] & kLeafPrimMask]; }
+        if (!TABLES) { const uint32_t row = hw[0] != kPrimNone ? hw[0] & kLeafPrimMask : 0u; buf[0].sph = S.sph[row]; buf[0].mat = S.prim_att[row]; }
     }
     const uint32_t n_tiles = (count + 63u) >> 6;
     // one cursor update for every path known to end; the answer is not needed before step 3
@@ -998,7 +1013,7 @@ __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads) void k
 #pragma unroll
     for (uint32_t t = 0; t < 4u; t++) {
         if (t < n_tiles) {
-            if (t + 1u < 4u) load_slot<!TABLES, MOVING, TABLES>(S, P, lane + 64u * (t + 1u) < count, sq[(t + 1u) & 3u], hw[(t + 1u) & 3u], buf[(t + 1u) & 1u]);
+            if (t + 1u < 4u) load_slot<!TABLES, MOVING, TABLES>(S, P, sq[(t + 1u) & 3u], hw[(t + 1u) & 3u], buf[(t + 1u) & 1u]);
             const uint32_t pos = lane + 64u * t;
             const uint32_t cls = (classes >> (4u * t)) & 15u;
             bool alive = false, absorbed = false, started = false;
@@ -1030,7 +1045,9 @@ __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads) void k
                 first_fetch = false;
                 have = min(gen_end, end_hi);
             }
-            if (pos < count) shade_slot<MOVING, Tables>(S, T, P, Bt, cls, sq[t], buf[t & 1u], l_ent[pos], np, alive, absorbed, started);
+            uint32_t slot = sq[t];
+            __asm__ volatile("" : "+v"(slot));  // as in load_slot: the store addresses are worked out from the slot number when they are needed
+            if (pos < count) shade_slot<MOVING, Tables>(S, T, P, Bt, cls, slot, buf[t & 1u], l_ent[pos], np, alive, absorbed, started);
             absorbed_bits |= absorbed ? (1u << t) : 0u;
             alive_bits |= alive ? (1u << t) : 0u;
             n_started += (uint32_t)__popcll(__ballot(started));
