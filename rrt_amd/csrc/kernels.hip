@@ -886,6 +886,10 @@ __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads, TABLES
 #endif
     using Tables = typename std::conditional<TABLES, LdsTables, GlobalTables>::type;
     Tables T;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = P.wave_begin + ((blockIdx.x * kThreads + threadIdx.x) >> 6);
+    // asked for before the tables so that the two round trips overlap (a wave past the end of the part reads the last list's)
+    const uint32_t count_word = P.qcount[min(wave, P.wave_end - 1u)];
     if (TABLES) {
         uint4 *tab = lds4 + (kThreads / 64u) * (kShadeLdsWords / 4u);
         const uint4 *src_s = reinterpret_cast<const uint4 *>(S.sph), *src_a = reinterpret_cast<const uint4 *>(S.prim_att);
@@ -897,11 +901,9 @@ __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads, TABLES
         T.sph = S.sph;
         T.att = S.prim_att;
     }
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = P.wave_begin + ((blockIdx.x * kThreads + threadIdx.x) >> 6);
     const uint32_t base = wave * kWaveSlots;
     if (wave >= P.wave_end) return;
-    const uint32_t count = rfl(P.qcount[wave]);
+    const uint32_t count = rfl(count_word);
     if (count == 0) return;
     // one 16-byte entry per list position: the slot's generator state; after step 3 the same memory holds step 4's
     // list of slots to refill
