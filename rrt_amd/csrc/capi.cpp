@@ -473,6 +473,7 @@ int render_queued(rrt_ctx *c, const rrt_render_params &P, const RenderTarget &T,
         }
         const uint64_t total_paths = (uint64_t)ns_local * npix;
         uint32_t chunk = kChunk;
+        const bool can_finish = finish_fits(sd, ps) && !std::getenv("RRT_NO_FINISH");
         for (uint32_t s0 = 0; s0 < ns_local; s0 += batch) {
             const uint32_t nb = std::min(batch, ns_local - s0);
             BatchDev bd{};
@@ -488,8 +489,16 @@ int render_queued(rrt_ctx *c, const rrt_render_params &P, const RenderTarget &T,
             bd.alive_flag = nullptr;  // raygen's survivors are not looked at
             HIP_TRY(hipMemsetAsync(bd.cursors, 0, (size_t)kCursorShards * kCursorStride * 4, s));
             launch_raygen(s, ps, bd, c->cam, wstats);
+            // Once every path of the batch has been dealt (at once, if the batch is no larger than the pool), what is left
+            // thins out over up to max_depth more rounds: where the scene allows it, one launch runs them all.
+            bool dealt = can_finish && (uint64_t)bd.n_paths <= slots;
             for (;;) {
                 HIP_TRY(hipMemsetAsync(flags, 0, kFlagWords * 4, s));
+                if (dealt) {
+                    if (launch_finish(s, sd, ps, bd, c->cam, c->moving, count, P.max_depth + 2u, retire_min, leaf_min, flags, wstats))
+                        return fail(RRT_ERR_HIP, "rrt_render: the finishing kernel's LDS request was refused");
+                    st.iterations += 1;
+                } else {
                 if (n_parts > 1) {
                     HIP_TRY(hipEventRecord(c->ev_fork, s));
                     for (uint32_t h = 1; h < n_parts; h++) HIP_TRY(hipStreamWaitEvent(part_stream[h], c->ev_fork, 0));
@@ -510,13 +519,22 @@ int render_queued(rrt_ctx *c, const rrt_render_params &P, const RenderTarget &T,
                 }
                 st.iterations += chunk;
                 chunk = std::min(kMaxChunk, chunk * 2u);
-                HIP_TRY(hipGetLastError());
                 for (uint32_t h = 1; h < n_parts; h++) { HIP_TRY(hipEventRecord(c->ev_join[h - 1], part_stream[h])); HIP_TRY(hipStreamWaitEvent(s, c->ev_join[h - 1], 0)); }
+                }
+                HIP_TRY(hipGetLastError());
                 HIP_TRY(hipMemcpyAsync(c->h_flags, flags, kFlagWords * 4, hipMemcpyDeviceToHost, s));
-                if (T.progress) HIP_TRY(hipMemcpyAsync(c->h_flags + kFlagWords, cursors, (size_t)kCursorShards * kCursorStride * 4, hipMemcpyDeviceToHost, s));
+                if (T.progress || (can_finish && !dealt))
+                    HIP_TRY(hipMemcpyAsync(c->h_flags + kFlagWords, cursors, (size_t)kCursorShards * kCursorStride * 4, hipMemcpyDeviceToHost, s));
                 HIP_TRY(hipStreamSynchronize(s));
                 uint32_t any = 0;
                 for (uint32_t k = 0; k < kFlagWords; k += 32) any |= c->h_flags[k];
+                if (can_finish && !dealt) {  // dealt: the next claim of every cursor shard lies past the batch (kernels.hip: path_of_claim)
+                    dealt = true;
+                    for (uint32_t k = 0; k < bd.n_shards && dealt; k++) {
+                        const uint64_t n = c->h_flags[kFlagWords + k * kCursorStride];
+                        if (((n >> 6) * bd.n_shards + k) * 64ull + (n & 63u) < (uint64_t)bd.n_paths) dealt = false;
+                    }
+                }
                 if (T.progress) {
                     // Paths handed out so far, less those that may still be in flight, are finished; a pixel counts as
                     // finished in proportion to its finished samples (the reference bumps its counter per pixel, lib.rs:109)

@@ -105,6 +105,12 @@ void launch_extend(hipStream_t s, const SceneDev &S, const PathState &P, bool mo
                    uint32_t leaf_min, uint64_t *wave_stats);
 void launch_shade(hipStream_t s, const SceneDev &S, const PathState &P, const BatchDev &B, const CameraDev &C, bool moving,
                   bool count, uint64_t *wave_stats);
+// The rest of a batch in one launch: every wave runs extend and shade on its own list until the list is empty (at most
+// max_rounds turns; a wave that stops with paths left raises alive_flag).  finish_fits says whether the scene and the
+// state layout allow it (BVH image and tables in LDS together); launch_finish returns nonzero if HIP refused the set-up.
+bool finish_fits(const SceneDev &S, const PathState &P);
+int launch_finish(hipStream_t s, const SceneDev &S, const PathState &P, const BatchDev &B, const CameraDev &C, bool moving,
+                  bool count, uint32_t max_rounds, uint32_t retire_min, uint32_t leaf_min, uint32_t *alive_flag, uint64_t *wave_stats);
 // accum[3][npix] += radiance of the batch's paths, sample by sample in order (lib.rs:96-103)
 void launch_accumulate(hipStream_t s, float *accum, uint32_t npix, const float4 *rad, uint32_t n_samples,
                        bool first_batch);

@@ -9,7 +9,10 @@
 //
 // Arithmetic follows the reference operation for operation: compiled with -ffp-contract=off, fused
 // multiply-adds only where ultraviolet's dot/mag use mul_add, IEEE division and square root.
+#include <mutex>
+#include <set>
 #include <type_traits>
+#include <utility>
 
 #include "kernels.h"
 #include "scene_layout.h"
@@ -876,38 +879,14 @@ DEV NewPath fetch_path(const NewPath &g, int src) {
     return r;
 }
 
-template <bool MOVING, bool COUNT, bool TABLES>
-__global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads, TABLES ? 4 : 3) void k_shade(SceneDev S, PathState P, BatchDev Bt, CameraDev C,
-                                                                                      uint64_t *wave_stats) {
-    constexpr uint32_t kThreads = TABLES ? kShadeTableThreads : kBlockThreads;
-    extern __shared__ uint4 lds4[];  // per wave kShadeLdsWords words, then (TABLES) the sphere and material tables
-#ifdef RRT_WAVE_TIMING
-    const uint64_t wt0 = wall_clock64();
-#endif
-    using Tables = typename std::conditional<TABLES, LdsTables, GlobalTables>::type;
-    Tables T;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = P.wave_begin + ((blockIdx.x * kThreads + threadIdx.x) >> 6);
-    // asked for before the tables so that the two round trips overlap (a wave past the end of the part reads the last list's)
-    const uint32_t count_word = P.qcount[min(wave, P.wave_end - 1u)];
-    if (TABLES) {
-        uint4 *tab = lds4 + (kThreads / 64u) * (kShadeLdsWords / 4u);
-        const uint4 *src_s = reinterpret_cast<const uint4 *>(S.sph), *src_a = reinterpret_cast<const uint4 *>(S.prim_att);
-        for (uint32_t i = threadIdx.x; i < S.n_spheres; i += kThreads) { tab[i] = src_s[i]; tab[S.n_spheres + i] = src_a[i]; }
-        __syncthreads();
-        T.sph = reinterpret_cast<const float4 *>(tab);
-        T.att = reinterpret_cast<const float4 *>(tab + S.n_spheres);
-    } else {
-        T.sph = S.sph;
-        T.att = S.prim_att;
-    }
+// One wave shades its list of `count` (> 0) live slots; returns the length of the list it leaves behind.  `l_ent` is the
+// wave's 4 KB of LDS (one 16-byte entry per list position: the slot's generator state; after step 3 the same memory
+// holds step 4's list of slots to refill).
+template <bool MOVING, bool COUNT, class Tables>
+DEV uint32_t shade_wave(const SceneDev &S, const PathState &P, const BatchDev &Bt, const CameraDev &C, const Tables &T, uint4 *l_ent,
+                        uint32_t wave, uint32_t lane, uint32_t count, uint64_t *wave_stats) {
+    constexpr bool TABLES = Tables::kInLds;
     const uint32_t base = wave * kWaveSlots;
-    if (wave >= P.wave_end) return;
-    const uint32_t count = rfl(count_word);
-    if (count == 0) return;
-    // one 16-byte entry per list position: the slot's generator state; after step 3 the same memory holds step 4's
-    // list of slots to refill
-    uint4 *l_ent = lds4 + (threadIdx.x >> 6) * (kShadeLdsWords / 4u);
     uint32_t *l_slot = reinterpret_cast<uint32_t *>(l_ent);
     const uint32_t shard = wave % Bt.n_shards;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
@@ -1102,9 +1081,6 @@ __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads, TABLES
             at += (uint32_t)__popcll(am[t]);
         }
     }
-#ifdef RRT_WAVE_TIMING
-    if (lane == 0) { uint64_t *w = wave_stats + (size_t)wave * kWaveStatWords; w[13] += wall_clock64() - wt0; w[14] += 1; }
-#endif
     if (lane == 0) {
         P.qcount[wave] = out_count;
         if (out_count && Bt.alive_flag) Bt.alive_flag[(wave & 31u) * 32u] = 1u;  // 32 lines share the traffic
@@ -1118,6 +1094,91 @@ __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads, TABLES
             st[ST_DEPTHCUT] += c_ev[4]; st[ST_ABSORBED] += (uint32_t)n_need;
         }
     }
+    return out_count;
+}
+
+template <bool MOVING, bool COUNT, bool TABLES>
+__global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads, TABLES ? 4 : 3) void k_shade(SceneDev S, PathState P, BatchDev Bt, CameraDev C,
+                                                                                      uint64_t *wave_stats) {
+    constexpr uint32_t kThreads = TABLES ? kShadeTableThreads : kBlockThreads;
+    extern __shared__ uint4 lds4[];  // per wave kShadeLdsWords words, then (TABLES) the sphere and material tables
+#ifdef RRT_WAVE_TIMING
+    const uint64_t wt0 = wall_clock64();
+#endif
+    using Tables = typename std::conditional<TABLES, LdsTables, GlobalTables>::type;
+    Tables T;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = P.wave_begin + ((blockIdx.x * kThreads + threadIdx.x) >> 6);
+    // asked for before the tables so that the two round trips overlap (a wave past the end of the part reads the last list's)
+    const uint32_t count_word = P.qcount[min(wave, P.wave_end - 1u)];
+    if (TABLES) {
+        uint4 *tab = lds4 + (kThreads / 64u) * (kShadeLdsWords / 4u);
+        const uint4 *src_s = reinterpret_cast<const uint4 *>(S.sph), *src_a = reinterpret_cast<const uint4 *>(S.prim_att);
+        for (uint32_t i = threadIdx.x; i < S.n_spheres; i += kThreads) { tab[i] = src_s[i]; tab[S.n_spheres + i] = src_a[i]; }
+        __syncthreads();
+        T.sph = reinterpret_cast<const float4 *>(tab);
+        T.att = reinterpret_cast<const float4 *>(tab + S.n_spheres);
+    } else {
+        T.sph = S.sph;
+        T.att = S.prim_att;
+    }
+    if (wave >= P.wave_end) return;
+    const uint32_t count = rfl(count_word);
+    if (count == 0) return;
+    shade_wave<MOVING, COUNT, Tables>(S, P, Bt, C, T, lds4 + (threadIdx.x >> 6) * (kShadeLdsWords / 4u), wave, lane, count, wave_stats);
+#ifdef RRT_WAVE_TIMING
+    if (lane == 0) { uint64_t *w = wave_stats + (size_t)wave * kWaveStatWords; w[13] += wall_clock64() - wt0; w[14] += 1; }
+#endif
+}
+
+// The end of a batch in one launch (scenes whose BVH image and tables fit in LDS together).  Once every path of the
+// batch has been dealt, rounds get ever shorter: the surviving paths thin out over up to max_depth more bounces, and a
+// round of two launches costs its launch latency however little it carries.  Here a wave runs extend and shade on its own
+// list, turn by turn, until the list is empty: the lists of different waves share nothing but the path cursor.  (Also the
+// whole of a render that is smaller than the path pool.  Before the paths are all dealt it would still be right, only
+// slower than the two kernels: extend wants twice the waves that shade's registers leave room for.)
+constexpr uint32_t kFinishThreads = 1024;
+template <bool MOVING, bool COUNT>
+__global__ __launch_bounds__(kFinishThreads, 4) void k_finish(SceneDev S, PathState P, BatchDev Bt, CameraDev C, uint32_t max_rounds,
+                                                              uint32_t retire_min, uint32_t leaf_min, uint32_t *alive_flag,
+                                                              uint64_t *wave_stats) {
+    extern __shared__ uint4 lds4[];  // the BVH image (at LDS address 0, as LdsStore wants it), 4 KB per wave, the tables
+    const uint32_t n_vec = (S.small_bytes + 15u) / 16u;
+    uint4 *ents = lds4 + n_vec;
+    uint4 *tab = ents + (kFinishThreads / 64u) * (kShadeLdsWords / 4u);
+    const uint4 *src_s = reinterpret_cast<const uint4 *>(S.sph), *src_a = reinterpret_cast<const uint4 *>(S.prim_att);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = P.wave_begin + blockIdx.x * (kFinishThreads / 64u) + (threadIdx.x >> 6);
+    uint32_t count = P.qcount[min(wave, P.wave_end - 1u)];
+    {   // nothing left in this workgroup's lists: leave before the copies (no static LDS: the image must start at address 0)
+        uint32_t *any = reinterpret_cast<uint32_t *>(ents);
+        if (threadIdx.x == 0) *any = 0u;
+        __syncthreads();
+        if (wave < P.wave_end && count != 0u && lane == 0) *any = 1u;
+        __syncthreads();
+        if (*any == 0u) return;
+    }
+    for (uint32_t i = threadIdx.x; i < n_vec; i += kFinishThreads) lds4[i] = S.small_nodes[i];
+    for (uint32_t i = threadIdx.x; i < S.n_spheres; i += kFinishThreads) { tab[i] = src_s[i]; tab[S.n_spheres + i] = src_a[i]; }
+    __syncthreads();
+    if (wave >= P.wave_end) return;
+    count = rfl(count);
+    LdsTables T;
+    T.sph = reinterpret_cast<const float4 *>(tab);
+    T.att = reinterpret_cast<const float4 *>(tab + S.n_spheres);
+    const LdsStore<MOVING> st(S.small_root, S.small_end);
+    uint4 *l_ent = ents + (threadIdx.x >> 6) * (kShadeLdsWords / 4u);
+    for (uint32_t round = 0; round < max_rounds && count != 0u; round++) {
+        extend_wave<LdsStore<MOVING>, MOVING, COUNT>(st, S, P, wave, lane, retire_min, leaf_min, wave_stats, count, nullptr, 0u, 0u);
+        // what one lane stored the next step may read in another lane: every store has to have reached the cache the
+        // wave reads through
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        count = shade_wave<MOVING, COUNT, LdsTables>(S, P, Bt, C, T, l_ent, wave, lane, count, wave_stats);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    if (count != 0u && lane == 0 && alive_flag) alive_flag[(wave & 31u) * 32u] = 1u;
 }
 
 __global__ void k_accumulate(float *accum, uint32_t npix, const float4 *rad, uint32_t n_samples, int first) {
@@ -1277,6 +1338,44 @@ void launch_shade(hipStream_t s, const SceneDev &S, const PathState &P, const Ba
         if (count) hipLaunchKernelGGL((k_shade<false, true, false>), g, b, lds, s, S, P, B, C, wave_stats);
         else hipLaunchKernelGGL((k_shade<false, false, false>), g, b, lds, s, S, P, B, C, wave_stats);
     }
+}
+
+bool finish_fits(const SceneDev &S, const PathState &P) {
+    return S.small_nodes != nullptr && (P.layout & kLayoutNarrow) != 0u && S.n_spheres <= kShadeTableSpheres;
+}
+
+int launch_finish(hipStream_t s, const SceneDev &S, const PathState &P, const BatchDev &B, const CameraDev &C, bool moving,
+                  bool count, uint32_t max_rounds, uint32_t retire_min, uint32_t leaf_min, uint32_t *alive_flag, uint64_t *wave_stats) {
+    const uint32_t wpb = kFinishThreads / 64u;
+    const dim3 g((P.wave_end - P.wave_begin + wpb - 1u) / wpb), b(kFinishThreads);
+    const size_t lds = (((size_t)S.small_bytes + 15u) & ~(size_t)15u) + (size_t)wpb * kShadeLdsWords * 4u + (size_t)S.n_spheres * 32u;
+    // more than 64 KB of LDS per workgroup has to be asked for once per kernel and device
+    static std::mutex mu;
+    static std::set<std::pair<int, int>> allowed;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 1;
+    const int variant = (moving ? 2 : 0) | (count ? 1 : 0);
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!allowed.count({dev, variant})) {
+            const void *f = variant == 3 ? reinterpret_cast<const void *>(&k_finish<true, true>)
+                          : variant == 2 ? reinterpret_cast<const void *>(&k_finish<true, false>)
+                          : variant == 1 ? reinterpret_cast<const void *>(&k_finish<false, true>)
+                                         : reinterpret_cast<const void *>(&k_finish<false, false>);
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 1;
+            allowed.insert({dev, variant});
+        }
+    }
+    BatchDev Bq = B;
+    Bq.alive_flag = nullptr;  // a wave reports once, when it stops, not after every round
+    if (moving) {
+        if (count) hipLaunchKernelGGL((k_finish<true, true>), g, b, lds, s, S, P, Bq, C, max_rounds, retire_min, leaf_min, alive_flag, wave_stats);
+        else hipLaunchKernelGGL((k_finish<true, false>), g, b, lds, s, S, P, Bq, C, max_rounds, retire_min, leaf_min, alive_flag, wave_stats);
+    } else {
+        if (count) hipLaunchKernelGGL((k_finish<false, true>), g, b, lds, s, S, P, Bq, C, max_rounds, retire_min, leaf_min, alive_flag, wave_stats);
+        else hipLaunchKernelGGL((k_finish<false, false>), g, b, lds, s, S, P, Bq, C, max_rounds, retire_min, leaf_min, alive_flag, wave_stats);
+    }
+    return 0;
 }
 
 void launch_accumulate(hipStream_t s, float *accum, uint32_t npix, const float4 *rad, uint32_t n_samples,

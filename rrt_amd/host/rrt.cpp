@@ -402,20 +402,27 @@ std::vector<uint8_t> tracescene(size_t nx, size_t ny, size_t ns, const Scene &sc
     // while it renders; a helper thread forwards the increments to `pdc` so that a poller of `pdc` sees them.
     volatile uint64_t done = 0;
     uint64_t forwarded = 0;
-    std::atomic<bool> finished{false};
+    bool finished = false;
+    std::mutex mu;
+    std::condition_variable wake;
     auto forward = [&] {
         const uint64_t now = done;
         if (now > forwarded) { pdc.fetch_add(static_cast<size_t>(now - forwarded), std::memory_order_relaxed); forwarded = now; }
     };
-    std::thread relay([&] {
-        while (!finished.load(std::memory_order_acquire)) {
+    std::thread relay([&] {  // looks every 20 ms, and leaves at once when the render returns
+        std::unique_lock<std::mutex> lock(mu);
+        while (!finished) {
             forward();
-            std::this_thread::sleep_for(std::chrono::milliseconds(20));
+            wake.wait_for(lock, std::chrono::milliseconds(20));
         }
     });
     // one GPU: rrt_render; several: tile shards, combined over RCCL on the first GPU (bit-identical either way)
     const int rc = rrt_render_multi(pool.contexts().data(), static_cast<uint32_t>(pool.contexts().size()), &p, pixels.data(), nullptr, nullptr, &done);
-    finished.store(true, std::memory_order_release);
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        finished = true;
+    }
+    wake.notify_one();
     relay.join();
     if (rc != RRT_OK) throw std::runtime_error(std::string("tracescene: ") + rrt_last_error());
     forward();  // the rest, up to nx*ny
