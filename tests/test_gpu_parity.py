@@ -156,6 +156,29 @@ def test_pool_parts_and_streams_do_not_change_the_image(gpu_ctx, monkeypatch):
         assert_same_image(gpu, ref)
 
 
+def test_finishing_launch_and_plain_rounds_agree(gpu_ctx, monkeypatch):
+    """The end of a batch runs as one launch (a wave loops over extend and shade on its own list) where the scene allows
+    it; RRT_NO_FINISH=1 keeps launching rounds instead.  Same image, same work counters, for a render bigger than the
+    pool and for one that fits the pool whole (then the single launch is the entire render)."""
+    osc = OracleScene.build(SCENES["book2chap2"], 160, 100, seed=2)
+    upload_from_oracle(gpu_ctx, osc)
+    for ns, slots in [(16, 64 * 1024), (3, 0)]:
+        ref = osc.render(160, 100, ns, seed=6, threads=8)
+        runs = []
+        for off in (False, True):
+            if off:
+                monkeypatch.setenv("RRT_NO_FINISH", "1")
+            else:
+                monkeypatch.delenv("RRT_NO_FINISH", raising=False)
+            gpu = gpu_ctx.render(rrt_amd.Context.params(160, 100, ns, seed=6, path_slots=slots, count_work=True))
+            assert_same_image(gpu, ref)
+            for k in ("rays", "inner_visits", "leaf_tests", "paths"):
+                assert gpu[2][k] == ref[2][k], (k, off)
+            runs.append(gpu[2]["iterations"])
+        assert runs[0] < runs[1]  # the finishing launch stands for many rounds
+    monkeypatch.delenv("RRT_NO_FINISH", raising=False)
+
+
 def test_tile_sharding_composes_to_the_unsharded_image(gpu_ctx):
     nx, ny, ns = 100, 37, 6   # not a multiple of the 32x8 tile in either direction
     osc = OracleScene.build(SCENES["chap12"], nx, ny, seed=0)
