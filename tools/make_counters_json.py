@@ -9,7 +9,7 @@ Definitions (MI355X guide units: SQ_ACTIVE_INST_* and SQ_WAVE_CYCLES count quad-
                      issues in 2.3 cycles (v_fma/v_add/v_mul/v_sub_f32, v_add_u32, v_and/or/xor, v_mov) still counts one quad-cycle.
   lane_util          SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU)
   lds_conflict_frac  SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
-  bytes_per_ray      (2 x FETCH_SIZE + WRITE_SIZE) x 1024 / rays, per kernel, default (four-stream) run; FETCH_SIZE doubled per
+  bytes_per_ray      (2 x FETCH_SIZE + WRITE_SIZE) x 1024 / rays, per kernel, default (two-stream) run; FETCH_SIZE doubled per
                      the gfx950 rule for 16-byte-per-lane streaming loads
 """
 import json
@@ -48,7 +48,7 @@ def main():
     one_sq, one_sq2 = parse(P(f"{tag}_1stream_pmc_sq.txt")), parse(P(f"{tag}_1stream_pmc_sq2.txt"))
     fetch, write = parse(P(f"{tag}_pmc_fetch.txt")), parse(P(f"{tag}_pmc_write.txt"))
     multi_sq, multi_sq2 = parse(P(f"{tag}_pmc_sq.txt")), parse(P(f"{tag}_pmc_sq2.txt"))
-    res = {"source": f"profiles/{tag}_pmc_*.txt (default run, four pool parts on four streams) and profiles/{tag}_1stream_pmc_*.txt "
+    res = {"source": f"profiles/{tag}_pmc_*.txt (default run, two pool parts on two streams) and profiles/{tag}_1stream_pmc_*.txt "
                      "(RRT_STREAMS=1); rocprofv3 --pmc, separate passes, bench.py --steps 1 --warmup 0, chap12 1200x800x500",
            "definitions": __doc__.split("Definitions")[1].strip()}
     bpr = {}
@@ -70,7 +70,7 @@ def main():
             with open(P("extend_traffic.json"), "w") as fo:
                 json.dump({"kernel": k1, "source": f"profiles/{tag}_pmc_fetch.txt + profiles/{tag}_pmc_write.txt", "fetch_size_kb_per_launch": round(f["FETCH_SIZE"] / f["dispatches"], 1),
                            "write_size_kb_per_launch": round(w["WRITE_SIZE"] / w["dispatches"], 1), "fetch_correction": 2.0, "bytes_per_launch": round(per),
-                           "note": "FETCH_SIZE doubled per the gfx950 rule for 16-byte-per-lane streaming loads; a launch is one quarter of the 4 Mi-slot path pool"}, fo)
+                           "note": "FETCH_SIZE doubled per the gfx950 rule for 16-byte-per-lane streaming loads; a launch is one half of the 4 Mi-slot path pool"}, fo)
     bpr["total"] = round(bpr["extend"] + bpr["shade"], 1)
     res["bytes_per_ray"] = bpr
     # the whole step as it runs by default: VALU quad-cycles of both kernels over the step's wall time
