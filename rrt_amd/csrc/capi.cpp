@@ -473,7 +473,9 @@ int render_queued(rrt_ctx *c, const rrt_render_params &P, const RenderTarget &T,
         }
         const uint64_t total_paths = (uint64_t)ns_local * npix;
         uint32_t chunk = kChunk;
-        const bool can_finish = finish_fits(sd, ps) && !std::getenv("RRT_NO_FINISH");
+        // (not for the entry point that must allocate nothing: the finishing kernel spills a few registers, and the runtime
+        // allocates the memory spills go to when such a kernel is first launched)
+        const bool can_finish = !no_alloc && finish_fits(sd, ps) && !std::getenv("RRT_NO_FINISH");
         for (uint32_t s0 = 0; s0 < ns_local; s0 += batch) {
             const uint32_t nb = std::min(batch, ns_local - s0);
             BatchDev bd{};
