@@ -721,11 +721,35 @@ struct LdsTables {
 // A freshly generated path: camera ray and generator state (lib.rs:93-101)
 struct NewPath { float4 A, B; uint4 rng; bool ok; };
 
+// The product of attenuations of the trail levels below `j`, innermost first (lib.rs:62), onto a radiance: read back
+// eight levels per round so that a long path costs few memory round trips.
+template <class Tables>
+DEV void fold_trail(const PathState &P, const Tables &T, uint32_t slot, uint32_t j, float &rx, float &ry, float &rz) {
+    const uint32_t *tr = P.trail + trail_index(P, 0u, slot);
+    const size_t ns = 64u;  // level stride inside a 64-slot group
+    while (j > 0u) {
+        const uint32_t m = j < 8u ? j : 8u;
+        uint32_t pr[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; k++) pr[k] = k < m ? tr[(size_t)(j - 1u - k) * ns] : 0u;
+#pragma unroll
+        for (uint32_t half = 0; half < 8u; half += 4u) {
+            float4 at[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; k++) at[k] = T.material(pr[half + k]);
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; k++)
+                if (half + k < m) { rx = at[k].x * rx; ry = at[k].y * ry; rz = at[k].z * rz; }
+        }
+        j -= m;
+    }
+}
+
 // Step 3 for one lane.  `gw` is the slot's LDS entry: the generator state (before the accepted draw, for Lambertian and
 // metal).  `np` is the path that takes over the slot if this one ends here.
 template <bool MOVING, class Tables>
 DEV void shade_slot(const SceneDev &S, const Tables &T, const PathState &P, const BatchDev &Bt, uint32_t cls, uint32_t slot,  // Tables::kInLds: the narrow state layout
-                    const SlotIn &in, uint4 gw, const NewPath &np, bool &alive, bool &absorbed, bool &started) {
+                    const SlotIn &in, uint4 gw, const NewPath &np, bool &alive, bool &absorbed, bool &started, uint4 *ent, uint32_t &older) {
     const float4 A = in.A, B = in.B;
     const uint32_t depth = in.depth & 0xFFFFu;       // scatters so far
     const uint32_t trail_len = in.depth >> 16;       // of which recorded on the trail
@@ -744,11 +768,8 @@ DEV void shade_slot(const SceneDev &S, const Tables &T, const PathState &P, cons
     float inv_len = 0.0f;
     if (cls == CL_METAL || cls == CL_DIEL || cls == CL_SKY) inv_len = recip_rn(sqrt_rn(dot3(d, d)));
     if (cls == CL_SKY) {
-        // sky (lib.rs:66-70), then the product of attenuations innermost first (lib.rs:62).  The spheres scattered off
-        // on the way are read back from the trail, eight levels per round so that a long path costs few memory round
-        // trips.  Dielectric hits are not on the trail: their attenuation is (1,1,1) and x * 1 is x.
-        const uint32_t *tr = P.trail + trail_index(P, 0u, slot);
-        const size_t ns = 64u;  // level stride inside a 64-slot group
+        // sky (lib.rs:66-70), then the product of attenuations innermost first (lib.rs:62).  Dielectric hits are not on
+        // the trail: their attenuation is (1,1,1) and x * 1 is x.
         const float uy = d.y * inv_len;
         const float t = 0.5f * (uy + 1.0f);
         const float w = 1.0f - t;
@@ -765,22 +786,16 @@ DEV void shade_slot(const SceneDev &S, const Tables &T, const PathState &P, cons
             for (uint32_t k = 0; k < 4u; k++)
                 if (k < trail_len) { rx = at[k].x * rx; ry = at[k].y * ry; rz = at[k].z * rz; }
         }
-        uint32_t j = trail_len > 4u ? trail_len - 4u : 0u;
-        while (j > 0u) {
-            const uint32_t m = j < 8u ? j : 8u;
-            uint32_t pr[8];
-#pragma unroll
-            for (uint32_t k = 0; k < 8u; k++) pr[k] = k < m ? tr[(size_t)(j - 1u - k) * ns] : 0u;
-#pragma unroll
-            for (uint32_t half = 0; half < 8u; half += 4u) {
-                float4 at[4];
-#pragma unroll
-                for (uint32_t k = 0; k < 4u; k++) at[k] = T.material(pr[half + k]);
-#pragma unroll
-                for (uint32_t k = 0; k < 4u; k++)
-                    if (half + k < m) { rx = at[k].x * rx; ry = at[k].y * ry; rz = at[k].z * rz; }
-            }
-            j -= m;
+        // Levels older than those four are in the trail planes, a memory round trip away with the whole tile waiting.
+        // Where the caller can take them later (narrow state: a level count fits a byte) the path's radiance so far and
+        // its id wait in the slot's LDS entry, and the caller folds the older levels of all such paths of the wave in
+        // one go after the tiles; the planes keep them, the slot's next path writes none before its fifth scatter.
+        const uint32_t j = trail_len > 4u ? trail_len - 4u : 0u;
+        if (Tables::kInLds && j != 0u) {
+            older = j;
+            *ent = make_uint4(f2u(rx), f2u(ry), f2u(rz), pid);
+        } else {
+            fold_trail(P, T, slot, j, rx, ry, rz);
         }
         ended = true;
     } else if (cls == CL_CUT) {  // lib.rs:58-60
@@ -850,7 +865,7 @@ DEV void shade_slot(const SceneDev &S, const Tables &T, const PathState &P, cons
             absorbed = true;
         }
     }
-    if (ended || absorbed) {
+    if ((ended || absorbed) && older == 0u) {
         Bt.rad[pid] = make_float4(rx, ry, rz, 0.0f);  // one 16-byte store per finished path
     }
     if (ended && np.ok) {  // the slot's next path, generated beforehand (see k_shade)
@@ -984,6 +999,7 @@ DEV uint32_t shade_wave(const SceneDev &S, const PathState &P, const BatchDev &B
     // ---- 3. tiles ----
     uint32_t absorbed_bits = 0, alive_bits = 0;
     uint32_t n_started = 0;
+    uint32_t older_levels = 0;  // per column, a byte: trail levels still to be folded into the radiance parked in the slot's LDS entry
     const uint32_t claim0 = rfl(claim_lane0);
     // New paths for the slots whose path ends are generated 64 at a time with every lane busy (lane i makes the path of
     // the wave's ending slot gen_first + i) and stay in registers; the lane that owns an ending slot fetches its path
@@ -1028,7 +1044,9 @@ DEV uint32_t shade_wave(const SceneDev &S, const PathState &P, const BatchDev &B
             }
             uint32_t slot = sq[t];
             __asm__ volatile("" : "+v"(slot));  // as in load_slot: the store addresses are worked out from the slot number when they are needed
-            if (pos < count) shade_slot<MOVING, Tables>(S, T, P, Bt, cls, slot, buf[t & 1u], l_ent[pos], np, alive, absorbed, started);
+            uint32_t older = 0u;
+            if (pos < count) shade_slot<MOVING, Tables>(S, T, P, Bt, cls, slot, buf[t & 1u], l_ent[pos], np, alive, absorbed, started, &l_ent[pos], older);
+            older_levels |= older << (8u * t);
             absorbed_bits |= absorbed ? (1u << t) : 0u;
             alive_bits |= alive ? (1u << t) : 0u;
             n_started += (uint32_t)__popcll(__ballot(started));
@@ -1038,6 +1056,22 @@ DEV uint32_t shade_wave(const SceneDev &S, const PathState &P, const BatchDev &B
 #ifdef RRT_SHADE_TIMING
     const uint64_t tk3 = __builtin_readcyclecounter();
 #endif
+    // ---- 3b. the paths that ended in the sky with more than four trail levels: the older levels, one pass for all ----
+    if (TABLES) {
+        while (__ballot(older_levels != 0u) != 0ull) {
+            if (older_levels != 0u) {
+                const uint32_t t = (uint32_t)(__ffs((int)older_levels) - 1) >> 3;  // the lane's first column with levels left
+                const uint32_t j = (older_levels >> (8u * t)) & 0xFFu;
+                const uint32_t slot = t == 0u ? sq[0] : (t == 1u ? sq[1] : (t == 2u ? sq[2] : sq[3]));
+                const uint4 parked = l_ent[lane + 64u * t];
+                float rx = u2f(parked.x), ry = u2f(parked.y), rz = u2f(parked.z);
+                fold_trail(P, T, slot, j, rx, ry, rz);
+                Bt.rad[parked.w] = make_float4(rx, ry, rz, 0.0f);
+                older_levels &= ~(0xFFu << (8u * t));
+            }
+        }
+    }
+
     // ---- 4. slots whose path was absorbed take the next paths of the batch, if any are left ----
     uint32_t n_need = 0;
     uint32_t rank[4];  // position of an absorbed slot in the wave's refill list
