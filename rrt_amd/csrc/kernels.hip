@@ -189,6 +189,7 @@ struct RayCtx {
     f32x2 ox, oy, oz;  // per axis {origin, 1 / direction}: both ray operands of the slab arithmetic in one aligned register pair
     V3 d;
     float a;      // d.d (sphere.rs:71), the same for every sphere
+    float ra;     // 1 / a, correctly rounded (where quick_div_ok says so)
     float time, f_ray;
     float tmin, tmax;
     uint32_t oct;   // bit k set: 1/d[k] < 0 (acceleration.rs:230-231)
@@ -217,7 +218,28 @@ DEV void ray_load(RayCtx &r, float4 A, float4 B, float4 C, float tmin, float tma
     r.d = mk(B.x, B.y, B.z);
     r.time = A.w;
     r.a = C.w;
+    r.ra = recip_newton(r.a);
     ray_finish(r, tmin, tmax, S, uniform_times);
+}
+
+// n / a for the ray's a = d.d in three instructions instead of the division's eleven: with y the correctly rounded
+// 1 / a, q0 = n y is within an ulp of the quotient, the residual n - a q0 is exact in one fma, and q0 + residual y
+// rounds to the correctly rounded quotient (Markstein's correction; checked against n / a on 1.4e11 random and near-tie
+// cases, tools/micro/div_exact.hip).  That holds while no intermediate leaves the normal range.  Instead of looking at
+// every numerator, the caller looks at every ray once (quick_div_ok) in a scene whose spheres are bounded
+// (kSceneBounded) walked with t_min >= 2^-40:
+//   * a in [2^-30, 2^30], so y is the exact reciprocal rounded (recip_newton) and no direction component exceeds 2^15;
+//   * origin components up to 2^30 and centres up to 2^30 put |o - c| below 2^31 per component, |half_b| below 2^48,
+//     |c| below 2^64 and the numerators -half_b -+ sqrt(half_b^2 - a c) below 2^50: nothing overflows;
+//   * a numerator below 2^-80, where the residual could go subnormal, gives a quotient below 2^-50 by either
+//     route: under t_min, a rejected root whatever its last bits.
+DEV bool quick_div_ok(const RayCtx &r) {
+    return r.a >= 0x1p-30f && r.a <= 0x1p30f && fmaxf(fmaxf(fabsf(r.ox.x), fabsf(r.oy.x)), fabsf(r.oz.x)) <= 0x1p30f;
+}
+DEV float div_by_a(float n, const RayCtx &r, bool quick) {
+    if (!quick) return n / r.a;
+    const float q0 = n * r.ra;
+    return __builtin_fmaf(__builtin_fmaf(-r.a, q0, n), r.ra, q0);
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -369,7 +391,7 @@ DEV uint32_t visit_inner(const LdsStore<MOVING> &st, uint32_t cur, const RayCtx 
 // square root and divisions until many lanes need them was tried: lanes that wait for roots cost the descent passes as
 // many idle lanes as the batched root passes save.)
 template <class Store>
-DEV uint32_t visit_leaf(const Store &st, uint32_t cur, RayCtx &r) {
+DEV uint32_t visit_leaf(const Store &st, uint32_t cur, RayCtx &r, bool quick) {  // quick: wave-uniform, every ray of the wave passes quick_div_ok
     V3 c;
     float rr;
     uint32_t handle, exit_ref;
@@ -380,10 +402,10 @@ DEV uint32_t visit_leaf(const Store &st, uint32_t cur, RayCtx &r) {
     const float disc = (half_b * half_b) - (r.a * cc);
     if (!(disc < 0.0f)) {
         const float sq = sqrt_rn(disc);
-        float root = (-half_b - sq) / r.a;
+        float root = div_by_a(-half_b - sq, r, quick);
         bool outside = root < r.tmin || r.tmax < root;
         if (outside) {
-            root = (-half_b + sq) / r.a;
+            root = div_by_a(-half_b + sq, r, quick);
             outside = root < r.tmin || r.tmax < root;
         }
         if (!outside) { r.tmax = root; r.best = handle; }
@@ -432,6 +454,8 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
     RayCtx r;
     ray_load(r, make_float4(0, 0, 0, 0), make_float4(1, 1, 1, 0), make_float4(1, 1, 1, 3), 0.001f, __FLT_MAX__, S, false);
     uint32_t cur = kEnd;
+    const bool may_quick = !MOVING && (S.flags & kSceneBounded) != 0u && P.t_min >= 0x1p-40f;
+    bool quick = false;  // wave-uniform: every ray the wave holds may be divided the short way (div_by_a)
     for (;;) {
         const bool idle = cur == kEnd;
         const uint64_t idle_m = __ballot(idle);
@@ -468,6 +492,7 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
                 cur = st.root();
                 has = true;
             }
+            quick = may_quick && __ballot(has && !quick_div_ok(r)) == 0ull;
             n_taken += (uint32_t)__popcll(__ballot(take));
             head += min(n_idle, count - head);  // pooled: reaches `count` once a grab runs past the end of the pool
             if (__ballot(has) == 0ull) break;
@@ -495,7 +520,7 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
         if (COUNT) { const uint64_t lm = __ballot(cur > kEnd); if (lm) { d_leaf_iters++; d_leaf_lanes += (uint32_t)__popcll(lm); } }
         if (cur > kEnd) {
             if (COUNT) n_leaf++;
-            cur = visit_leaf(st, cur, r);
+            cur = visit_leaf(st, cur, r, quick);
         }
     }
     uint64_t *stt = wave_stats + (size_t)wave * kWaveStatWords;
@@ -535,7 +560,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_extend(SceneDev S, PathState 
 constexpr uint32_t kLdsBlockThreads = 1024;  // 16 waves share one LDS copy of the scene
 
 template <bool MOVING, bool COUNT>
-__global__ __launch_bounds__(kLdsBlockThreads, 8) void k_extend_lds(SceneDev S, PathState P, uint32_t retire_min, uint32_t leaf_min,
+__global__ __launch_bounds__(kLdsBlockThreads, 8) __attribute__((amdgpu_num_sgpr(48))) void k_extend_lds(SceneDev S, PathState P, uint32_t retire_min, uint32_t leaf_min,
                                                                   uint64_t *wave_stats) {
     extern __shared__ uint4 lds4[];
 #ifdef RRT_WAVE_TIMING

@@ -43,6 +43,7 @@ constexpr uint32_t kInfoMovingBit = 0x80000000u;
 // Scene flags
 constexpr uint32_t kSceneHasMoving = 1u;
 constexpr uint32_t kSceneUniformTimes = 2u;
+constexpr uint32_t kSceneBounded = 4u;  // no sphere moves, and every centre component and radius is finite and at most 2^30 in magnitude
 
 struct Float4 { float x, y, z, w; };
 
