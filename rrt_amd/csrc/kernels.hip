@@ -229,12 +229,15 @@ DEV void ray_load(RayCtx &r, float4 A, float4 B, float4 C, float tmin, float tma
 // every numerator, the caller looks at every ray once (quick_div_ok) in a scene whose spheres are bounded
 // (kSceneBounded) walked with t_min >= 2^-40:
 //   * a in [2^-30, 2^30], so y is the exact reciprocal rounded (recip_newton) and no direction component exceeds 2^15;
-//   * origin components up to 2^30 and centres up to 2^30 put |o - c| below 2^31 per component, |half_b| below 2^48,
-//     |c| below 2^64 and the numerators -half_b -+ sqrt(half_b^2 - a c) below 2^50: nothing overflows;
+//   * origin components up to 2^30 and centres up to 2^31 (a moving sphere's, with the ray's time inside the shutter
+//     interval all moving spheres share: 2^29 + 1 * 2^30) put |o - c| below 2^32 per component, |half_b| below 2^49,
+//     |c| below 2^66 and the numerators -half_b -+ sqrt(half_b^2 - a c) below 2^51: nothing overflows;
 //   * a numerator below 2^-80, where the residual could go subnormal, gives a quotient below 2^-50 by either
 //     route: under t_min, a rejected root whatever its last bits.
+template <bool MOVING>
 DEV bool quick_div_ok(const RayCtx &r) {
-    return r.a >= 0x1p-30f && r.a <= 0x1p30f && fmaxf(fmaxf(fabsf(r.ox.x), fabsf(r.oy.x)), fabsf(r.oz.x)) <= 0x1p30f;
+    return r.a >= 0x1p-30f && r.a <= 0x1p30f && fmaxf(fmaxf(fabsf(r.ox.x), fabsf(r.oy.x)), fabsf(r.oz.x)) <= 0x1p30f &&
+           (!MOVING || (r.f_ray >= 0.0f && r.f_ray <= 1.0f));
 }
 DEV float div_by_a(float n, const RayCtx &r, bool quick) {
     if (!quick) return n / r.a;
@@ -454,7 +457,7 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
     RayCtx r;
     ray_load(r, make_float4(0, 0, 0, 0), make_float4(1, 1, 1, 0), make_float4(1, 1, 1, 3), 0.001f, __FLT_MAX__, S, false);
     uint32_t cur = kEnd;
-    const bool may_quick = !MOVING && (S.flags & kSceneBounded) != 0u && P.t_min >= 0x1p-40f;
+    const bool may_quick = (S.flags & kSceneBounded) != 0u && P.t_min >= 0x1p-40f;
     bool quick = false;  // wave-uniform: every ray the wave holds may be divided the short way (div_by_a)
     for (;;) {
         const bool idle = cur == kEnd;
@@ -492,7 +495,7 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
                 cur = st.root();
                 has = true;
             }
-            quick = may_quick && __ballot(has && !quick_div_ok(r)) == 0ull;
+            quick = may_quick && __ballot(has && !quick_div_ok<MOVING>(r)) == 0ull;
             n_taken += (uint32_t)__popcll(__ballot(take));
             head += min(n_idle, count - head);  // pooled: reaches `count` once a grab runs past the end of the pool
             if (__ballot(has) == 0ull) break;

@@ -70,7 +70,7 @@ int build_scene_layout(const rrt_sphere_soa *sp, const rrt_material_soa *mt, con
         // into +0.0).  Only those spheres skip the interpolation; every other sphere evaluates it in full.
         bool still = f2u(sp->time0[i]) == 0u && sp->time1[i] == 1.0f;
         for (int k = 0; k < 3; k++) still = still && f2u(c0[k]) == f2u(c1[k]) && !is_neg_zero(c0[k]);
-        for (int k = 0; k < 3; k++) bounded = bounded && std::fabs(c0[k]) <= 0x1p30f;  // false for NaN
+        for (int k = 0; k < 3; k++) bounded = bounded && std::fabs(c0[k]) <= 0x1p29f && std::fabs(c1[k]) <= 0x1p29f;  // false for NaN
         bounded = bounded && std::fabs(sp->radius[i]) <= 0x1p30f;
         out.sph[i] = Float4{c0[0], c0[1], c0[2], sp->radius[i]};
         out.motion[i] = Float4{c1[0] - c0[0], c1[1] - c0[1], c1[2] - c0[2], sp->time0[i]};
@@ -92,7 +92,7 @@ int build_scene_layout(const rrt_sphere_soa *sp, const rrt_material_soa *mt, con
     }
     if (any_moving) out.flags |= kSceneHasMoving;
     if (any_moving && uniform) out.flags |= kSceneUniformTimes;
-    if (!any_moving && bounded) out.flags |= kSceneBounded;
+    if (bounded && (!any_moving || uniform)) out.flags |= kSceneBounded;
 
     // ---- tree validation: every node reachable from the root exactly once, indices in range ----
     std::vector<uint8_t> seen(n_nodes, 0);

@@ -43,7 +43,9 @@ constexpr uint32_t kInfoMovingBit = 0x80000000u;
 // Scene flags
 constexpr uint32_t kSceneHasMoving = 1u;
 constexpr uint32_t kSceneUniformTimes = 2u;
-constexpr uint32_t kSceneBounded = 4u;  // no sphere moves, and every centre component and radius is finite and at most 2^30 in magnitude
+// every centre component (both ends of a moving sphere's way) is at most 2^29 in magnitude and every radius at most 2^30,
+// and spheres that move share one shutter interval
+constexpr uint32_t kSceneBounded = 4u;
 
 struct Float4 { float x, y, z, w; };
 
