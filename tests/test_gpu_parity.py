@@ -65,6 +65,14 @@ def test_intersect_random_and_degenerate_rays(gpu_ctx, name):
     d[2000:4000, 1] = 0.0
     d[4000:6000, 2] = -0.0
     d[6000:6500, 0:2] = 0.0
+    # directions and origins outside the range in which the sphere roots are divided the short way (d.d beyond 2^+-30,
+    # origin components beyond 2^30): whole waves of them, and single rays inside waves that are otherwise in range
+    d[6500:8000] *= np.float32(1e6)
+    d[8000:9500] *= np.float32(1e-6)
+    org[9500:10000, 0] += np.float32(3e9)
+    d[12345] *= np.float32(1e6)
+    d[15000] *= np.float32(1e-6)
+    org[17777, 2] = np.float32(-2e9)
     tm = rng.uniform(0, 1, n).astype(np.float32)
     t_o, obj_o, _, _, _ = osc.hit_rays(org, d, tm)
     t_g, obj_g = gpu_ctx.intersect(org, d, tm)
