@@ -384,7 +384,7 @@ int render_queued(rrt_ctx *c, const rrt_render_params &P, const RenderTarget &T,
     HIP_TRY(hipEventRecord(c->ev0, s));
 
     const bool count = P.count_work != 0;
-    const uint32_t retire_min = P.reserved[2] ? std::min<uint32_t>(P.reserved[2], 64u) : 32u;  // tuning knob of the extend kernel
+    const uint32_t retire_min = P.reserved[2] ? std::min<uint32_t>(P.reserved[2], 64u) : 40u;  // tuning knob of the extend kernel
     const uint32_t leaf_min = P.reserved[3] ? std::min<uint32_t>(P.reserved[3], 64u) : 16u;
     SceneDev sd = c->sd;
     if (P.reserved[1] & 1u) sd.small_nodes = nullptr;  // walk the HBM copy of the BVH even if the scene fits in LDS
