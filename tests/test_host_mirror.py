@@ -148,18 +148,25 @@ def test_exit_links_reproduce_the_stack_order(kind):
         assert int(words[i, 4]) >> 30 == int(mt[mid[obj], 0])
         assert np.array_equal(words[i, 0:3], sp[obj, 0:3].view(np.uint32))
         assert words[i, 3] == np.float32(sp[obj, 8] * sp[obj, 8]).view(np.uint32)
-    assert flags == 0
+    assert flags == 4  # nothing moves; bit 2: every centre and radius is small enough for the short division of the sphere test
 
 
 def test_layout_flags_moving_scene():
     osc = OracleScene.build(2, 64, 64, seed=0)
     sp, mid, mt, nd, _ = scene_arrays_from_oracle(osc)
     words, root, flags = rrt_amd.debug_layout(sp, mid, mt, nd)
-    assert flags == 3  # has moving spheres, all with the same shutter interval
+    assert flags == 7  # has moving spheres, all with the same shutter interval, and bounded (bit 2)
     sp2 = sp.copy()
     k = np.nonzero((sp[:, 0:3] != sp[:, 3:6]).any(axis=1))[0][0]
     sp2[k, 7] = 2.0
-    assert rrt_amd.debug_layout(sp2, mid, mt, nd)[2] == 1
+    assert rrt_amd.debug_layout(sp2, mid, mt, nd)[2] == 1  # another shutter interval: not uniform, and then not "bounded" either
+    # a centre or a radius out of the short division's range takes bit 2 away and nothing else
+    for col, val in [(0, 3.0e9), (5, -1.0e9), (8, 2.0e9), (1, np.nan)]:
+        sp3 = sp.copy()
+        sp3[k, col] = val
+        if col < 3:
+            sp3[k, col + 3] = val  # keep centre1 - centre0 as it was in kind (the sphere stays a moving one)
+        assert rrt_amd.debug_layout(sp3, mid, mt, nd)[2] & 4 == 0
 
 
 def test_scene_validation_errors():
