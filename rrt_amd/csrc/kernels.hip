@@ -563,8 +563,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_extend(SceneDev S, PathState 
 constexpr uint32_t kLdsBlockThreads = 1024;  // 16 waves share one LDS copy of the scene
 
 template <bool MOVING, bool COUNT>
-__global__ __launch_bounds__(kLdsBlockThreads, 8) __attribute__((amdgpu_num_sgpr(48))) void k_extend_lds(SceneDev S, PathState P, uint32_t retire_min, uint32_t leaf_min,
-                                                                  uint64_t *wave_stats) {
+DEV void extend_lds_block(const SceneDev &S, const PathState &P, uint32_t retire_min, uint32_t leaf_min, uint64_t *wave_stats) {
     extern __shared__ uint4 lds4[];
 #ifdef RRT_WAVE_TIMING
     const uint64_t wt0 = wall_clock64();
@@ -599,6 +598,21 @@ __global__ __launch_bounds__(kLdsBlockThreads, 8) __attribute__((amdgpu_num_sgpr
         if (lane == 0) { uint64_t *w = wave_stats + (size_t)wave * kWaveStatWords; w[10] += wt2 - wt0; w[11] += wt1 - wt0; w[12] += 1; w[15] += wall_clock64() - wt2; }
     }
 #endif
+}
+
+// The kernel a render runs is held to 48 scalar registers: with more (the same code, nothing but the allocation) its
+// launches share the chip worse with the shade kernel's, 6 % of the step time with two streams; alone it runs the same.
+// The counting build does not fit in 48 without spilling and is not timed: it is a kernel of its own without the limit.
+template <bool MOVING, bool COUNT>
+__global__ __launch_bounds__(kLdsBlockThreads, 8) __attribute__((amdgpu_num_sgpr(48))) void k_extend_lds(SceneDev S, PathState P, uint32_t retire_min, uint32_t leaf_min,
+                                                                  uint64_t *wave_stats) {
+    static_assert(!COUNT, "the counting variant is k_count_extend_lds");
+    extend_lds_block<MOVING, false>(S, P, retire_min, leaf_min, wave_stats);
+}
+template <bool MOVING>
+__global__ __launch_bounds__(kLdsBlockThreads, 8) void k_count_extend_lds(SceneDev S, PathState P, uint32_t retire_min, uint32_t leaf_min,
+                                                                        uint64_t *wave_stats) {
+    extend_lds_block<MOVING, true>(S, P, retire_min, leaf_min, wave_stats);
 }
 
 // Scenes whose nodes stay in HBM: the top levels of the tree (every ray starts there) are walked in an LDS copy.
@@ -1344,10 +1358,10 @@ void launch_extend(hipStream_t s, const SceneDev &S, const PathState &P, bool mo
         const dim3 g((P.wave_end - P.wave_begin + waves_per_block - 1u) / waves_per_block), b(kLdsBlockThreads);
         const size_t lds = (((size_t)S.small_bytes + 15u) & ~(size_t)15u) + 16u;  // the image, then the pool counters
         if (moving) {
-            if (count) hipLaunchKernelGGL((k_extend_lds<true, true>), g, b, lds, s, S, P, retire_min, leaf_min, wave_stats);
+            if (count) hipLaunchKernelGGL((k_count_extend_lds<true>), g, b, lds, s, S, P, retire_min, leaf_min, wave_stats);
             else hipLaunchKernelGGL((k_extend_lds<true, false>), g, b, lds, s, S, P, retire_min, leaf_min, wave_stats);
         } else {
-            if (count) hipLaunchKernelGGL((k_extend_lds<false, true>), g, b, lds, s, S, P, retire_min, leaf_min, wave_stats);
+            if (count) hipLaunchKernelGGL((k_count_extend_lds<false>), g, b, lds, s, S, P, retire_min, leaf_min, wave_stats);
             else hipLaunchKernelGGL((k_extend_lds<false, false>), g, b, lds, s, S, P, retire_min, leaf_min, wave_stats);
         }
         return;
