@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised GPU-vs-oracle comparison: random scene, image size, sample count, depth limit, pool size, batch size, pool
-parts, every image compared bit for bit.  python tools/fuzz.py [seconds] [seed] [big]
+parts, with and without the finishing launch, every image compared bit for bit.  python tools/fuzz.py [seconds] [seed] [big]
 ("big": images large enough to fill the path pool, so that the workgroup-wide hand-out of the extend kernel is in use)"""
 import os
 import sys
@@ -24,13 +24,17 @@ while time.time() < t_end:
     half = int(rng.integers(3, 40)) if kind == 3 else 11
     nx, ny = (int(rng.integers(300, 700)), int(rng.integers(200, 420))) if big else (int(rng.integers(1, 200)), int(rng.integers(1, 120)))
     ns = int(rng.integers(4, 24)) if big else int(rng.integers(1, 20))
-    depth = int(rng.choice([0, 1, 3, 50]))
+    depth = int(rng.choice([0, 1, 3, 50, 50, 120, 300]))  # 300: past the narrow state's 255
     slots = int(rng.choice([256 * 64, 256 * 512, 256 * 1024, 256 * 4096])) if big else int(rng.choice([0, 256, 512, 4096, 256 * 33, 256 * 1024]))
     batch = int(rng.choice([0, 1, 3, 7]))
     parts = str(int(rng.integers(1, 5)))
     force_hbm = bool(rng.integers(0, 2))
     seed, scene_seed = int(rng.integers(0, 1 << 30)), int(rng.integers(0, 100))
     os.environ["RRT_STREAMS"] = parts
+    if rng.integers(0, 4) == 0:
+        os.environ["RRT_NO_FINISH"] = "1"  # rounds to the end instead of the finishing launch
+    else:
+        os.environ.pop("RRT_NO_FINISH", None)
     osc = OracleScene.build(kind, nx, ny, seed=scene_seed, half=half)
     sp, mid, mt, nd, cam21 = scene_arrays_from_oracle(osc)
     ctx.upload_scene(sp, mid, mt, nd)
