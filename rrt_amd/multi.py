@@ -57,6 +57,27 @@ def owned_pixels(nx: int, ny: int, mode: int, rank: int, world: int):
     return torch.from_numpy(rrt_amd.shard_pixels(nx, ny, mode, rank, world).astype(np.int64))
 
 
+_tile_cache: dict = {}
+
+
+def _tile_indices(nx: int, ny: int, rank: int, world: int, dst: int, device):
+    """Owner index lists of a TILE split, kept on `device` across calls (a 3840x2160 image is 8.3 M int64 indices: building
+    and uploading them belongs to set-up, not to every frame's combine).  Returns (counts per rank, this rank's indices,
+    every rank's indices on `dst` or None elsewhere)."""
+    key = (nx, ny, rank, world, dst, str(device))
+    hit = _tile_cache.get(key)
+    if hit is None:
+        counts = [int(rrt_amd.lib().rrt_shard_pixels(nx, ny, rrt_amd.SHARD_TILE, r, world, None)) for r in range(world)]
+        mine = owned_pixels(nx, ny, rrt_amd.SHARD_TILE, rank, world).to(device)
+        every = None
+        if rank == dst:
+            every = [mine if r == rank else owned_pixels(nx, ny, rrt_amd.SHARD_TILE, r, world).to(device) for r in range(world)]
+        if len(_tile_cache) >= 8:
+            _tile_cache.clear()
+        hit = _tile_cache[key] = (counts, mine, every)
+    return hit
+
+
 def gather_tiles(buf, nx: int, ny: int, rank: int, world: int, dst: int = 0):
     """Combines TILE shards of one image plane set.  `buf` is this rank's full-size buffer [ny*nx*3] (pixels it does not own
     are ignored).  Every rank sends the pixels it owns, padded to the largest share; `dst` puts them in place and returns the
@@ -64,9 +85,8 @@ def gather_tiles(buf, nx: int, ny: int, rank: int, world: int, dst: int = 0):
     import torch
     import torch.distributed as dist
 
-    counts = [int(rrt_amd.lib().rrt_shard_pixels(nx, ny, rrt_amd.SHARD_TILE, r, world, None)) for r in range(world)]
+    counts, mine, every = _tile_indices(nx, ny, rank, world, dst, buf.device)
     n_max = max(counts)
-    mine = owned_pixels(nx, ny, rrt_amd.SHARD_TILE, rank, world).to(buf.device)
     packed = torch.zeros((n_max, 3), dtype=buf.dtype, device=buf.device)
     packed[: counts[rank]] = buf.view(-1, 3)[mine]
     via_host = buf.is_cuda and dist.get_backend() == "gloo"  # rehearsals on a process group without device collectives
@@ -80,8 +100,7 @@ def gather_tiles(buf, nx: int, ny: int, rank: int, world: int, dst: int = 0):
         parts = [t.to(buf.device) for t in parts]
     out = torch.zeros_like(buf).view(-1, 3)
     for r in range(world):
-        idx = mine if r == rank else owned_pixels(nx, ny, rrt_amd.SHARD_TILE, r, world).to(buf.device)
-        out[idx] = parts[r][: counts[r]]
+        out[every[r]] = parts[r][: counts[r]]
     return out.view(-1)
 
 
