@@ -4,7 +4,8 @@
 HIPCC   ?= /opt/rocm/bin/hipcc
 ARCH    := gfx950   # the only target: the kernels use gfx950 instructions and its 160 KiB of LDS per CU
 FPFLAGS := -ffp-contract=off -fno-fast-math
-DEVFLAGS:= --offload-arch=$(ARCH) -fhip-fp32-correctly-rounded-divide-sqrt
+# no SLP vectorisation: packed f32 instructions issue at the rate of two scalar ones on gfx950, and pairing operands costs moves
+DEVFLAGS:= --offload-arch=$(ARCH) -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize
 CXXFLAGS:= -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wextra -Wno-unused-parameter $(FPFLAGS)
 
 LIB     := rrt_amd/librrt_amd.so

@@ -481,6 +481,7 @@ int render_queued(rrt_ctx *c, const rrt_render_params &P, const RenderTarget &T,
             BatchDev bd{};
             bd.nx = P.nx; bd.ny = P.ny; bd.npix = npix; bd.pixel_map = d_map;
             bd.div_nx = make_fastdiv(P.nx); bd.div_npix = make_fastdiv(npix);
+            bd.inv_nx = 1.0f / (float)P.nx; bd.inv_ny = 1.0f / (float)P.ny;
             bd.n_paths = nb * npix;
             bd.k_first = k_first + s0 * k_step; bd.k_step = k_step;
             bd.seed = P.seed;

@@ -89,6 +89,7 @@ struct BatchDev {
     uint32_t nx, ny;
     uint32_t npix;             // pixels this call renders
     FastDiv div_nx, div_npix;
+    float inv_nx, inv_ny;      // 1.0f / nx and 1.0f / ny, correctly rounded (IEEE division on the host)
     const uint32_t *pixel_map; // local pixel -> image pixel index (lib.rs:93-94 idx); null = identity
     uint32_t n_paths;          // npix * samples in this batch
     uint32_t k_first, k_step;  // sample index of local sample j is k_first + j * k_step

@@ -63,9 +63,15 @@ DEV float recip_rn(float x) {
     return q;
 }
 
-// ultraviolet normalized(): reciprocal of the magnitude, then one multiply per lane
-DEV V3 normalized(V3 a) { const float r = recip_rn(sqrt_rn(dot3(a, a))); return mk(a.x * r, a.y * r, a.z * r); }
-// the multiply half of normalized(): a * (1 / |a|), each component times the reciprocal
+// n / a in three instructions where y is the correctly rounded 1 / a: q0 = n y is within an ulp of the quotient, the
+// residual n - a q0 is exact in one fma, and q0 + residual y rounds to the correctly rounded quotient (Markstein's
+// correction; checked against n / a on 10^11 random and near-tie cases of either sign, tools/micro/div_exact.hip).  Holds
+// while no intermediate leaves the normal range; callers guard |a| in [2^-30, 2^30] and n either +0 with a > 0 or |n| in
+// [2^-90, 2^90].
+DEV float div_known(float n, float a, float y) { const float q0 = n * y; return __builtin_fmaf(__builtin_fmaf(-a, q0, n), y, q0); }
+
+// ultraviolet normalized() is the reciprocal of the magnitude, recip_rn(sqrt_rn(dot3(a, a))), then one multiply per
+// component: a * (1 / |a|).  This is the multiply half.
 DEV V3 scale_r(V3 a, float r) { return mk(a.x * r, a.y * r, a.z * r); }
 // ultraviolet reflected(): self - (2 * self.dot(n)) * n
 DEV V3 reflected(V3 i, V3 n) { const float k = 2.0f * dot3(i, n); return sub(i, scale(k, n)); }
@@ -87,7 +93,11 @@ DEV uint32_t next_u32(Rng &g) {
     return r;
 }
 DEV float gen_f32(Rng &g) { return (float)(next_u32(g) >> 8) * 0x1p-24f; }  // rand Standard
-DEV float sample_pm1(Rng &g) { const float v = (float)(next_u32(g) >> 9) * 0x1p-23f; return v * RRT_PM1_SCALE + -1.0f; }
+// rand's 23-bit uniform in [0, 1): (next_u32 >> 9) * 2^-23.  The 23 bits under the exponent of 1.0 are the float 1 + v, and
+// subtracting 1.0 from it is exact: the same value in two instructions (v_alignbit_b32, v_sub_f32) instead of a shift, a
+// conversion and a multiply.
+DEV float unit23(Rng &g) { return u2f(__builtin_amdgcn_alignbit(0x7Fu, next_u32(g), 9u)) - 1.0f; }
+DEV float sample_pm1(Rng &g) { return unit23(g) * RRT_PM1_SCALE + -1.0f; }
 
 DEV uint64_t splitmix64(uint64_t &st) {
     st += 0x9E3779B97F4A7C15ull;
@@ -126,8 +136,10 @@ DEV void generate_path(const BatchDev &Bt, const CameraDev &C, uint32_t p, float
     const uint32_t row = fd_div(idx, Bt.div_nx);
     const float x = (float)(idx - row * Bt.nx);
     const float y = (float)(Bt.ny - 1u - row);
-    const float s = (x + gen_f32(g)) / (float)Bt.nx;
-    const float t = (y + gen_f32(g)) / (float)Bt.ny;
+    // (x + r) / nx and (y + r) / ny (lib.rs:98-99) through the correctly rounded reciprocals the host supplies: the
+    // numerators are +0 or in [2^-24, 2^28) and the divisors in [1, 2^28], so div_known is the IEEE quotient bit for bit
+    const float s = div_known(x + gen_f32(g), (float)Bt.nx, Bt.inv_nx);
+    const float t = div_known(y + gen_f32(g), (float)Bt.ny, Bt.inv_ny);
     float dx, dy;
     for (;;) {  // rng.rs:42-50
         dx = sample_pm1(g); dy = sample_pm1(g);
@@ -139,7 +151,7 @@ DEV void generate_path(const BatchDev &Bt, const CameraDev &C, uint32_t p, float
     const V3 origin = add(mk(C.org[0], C.org[1], C.org[2]), offset);
     const V3 llc = mk(C.llc[0], C.llc[1], C.llc[2]), hor = mk(C.hor[0], C.hor[1], C.hor[2]), ver = mk(C.ver[0], C.ver[1], C.ver[2]);
     const V3 dir = sub(add(add(llc, scale(s, hor)), scale(t, ver)), origin);
-    const float tv = (float)(next_u32(g) >> 9) * 0x1p-23f;
+    const float tv = unit23(g);
     const float time = tv * C.time_scale + C.time_low;  // rand Uniform::sample (camera.rs:64)
     A = make_float4(origin.x, origin.y, origin.z, time);
     B = make_float4(dir.x, dir.y, dir.z, u2f(p));
@@ -806,9 +818,16 @@ DEV void shade_slot(const SceneDev &S, const Tables &T, const PathState &P, cons
     uint32_t o_depth = 0u;
     uint4 o_recent = in.recent;
     bool ended = false;
-    // 1 / |d|, shared by everything that needs the unit direction: the sky (lib.rs:67), metal (materials.rs:47) and glass (materials.rs:83)
+    // the draw step 2 accepted (Lambertian and metal), repeated from the generator state it left in the slot's entry
+    V3 smp = mk(0.0f, 0.0f, 0.0f);
+    if (cls <= CL_METAL) { smp.x = sample_pm1(g); smp.y = sample_pm1(g); smp.z = sample_pm1(g); }
+    // Every class but the depth cut normalises exactly one vector: the sample (Lambertian, rng.rs:52-55) or the direction
+    // (sky lib.rs:67, metal materials.rs:47, glass materials.rs:83).  One reciprocal magnitude serves whichever it is.
     float inv_len = 0.0f;
-    if (cls == CL_METAL || cls == CL_DIEL || cls == CL_SKY) inv_len = recip_rn(sqrt_rn(dot3(d, d)));
+    if (cls <= CL_SKY) {
+        const V3 v = cls == CL_LAMB ? smp : d;
+        inv_len = recip_rn(sqrt_rn(dot3(v, v)));
+    }
     if (cls == CL_SKY) {
         // sky (lib.rs:66-70), then the product of attenuations innermost first (lib.rs:62).  Dielectric hits are not on
         // the trail: their attenuation is (1,1,1) and x * 1 is x.
@@ -859,15 +878,25 @@ DEV void shade_slot(const SceneDev &S, const Tables &T, const PathState &P, cons
         // Hit record (sphere.rs:86-100)
         const V3 p = add(o, scale(t, d));
         const V3 pc = sub(p, c);
-        const V3 on = mk(pc.x / sp.w, pc.y / sp.w, pc.z / sp.w);
+        // outward normal (p - c) / radius (sphere.rs:88): through the reciprocal of the radius where every lane's operands
+        // are in div_known's range (the scene's radii by kSceneRadiiNormal, the numerators looked at here: a zero, a
+        // denormal, a NaN or a huge component sends the wave to the division)
+        V3 on;
+        {
+            const float lo = 0x1p-90f, hi = 0x1p90f;
+            const bool in_range = fabsf(pc.x) >= lo && fabsf(pc.x) <= hi && fabsf(pc.y) >= lo && fabsf(pc.y) <= hi && fabsf(pc.z) >= lo && fabsf(pc.z) <= hi;
+            float y = recip_newton(sp.w);
+            if (__builtin_expect((S.flags & kSceneRadiiNormal) != 0u && __ballot(!in_range || recip_suspect(y)) == 0ull, 1))
+                on = mk(div_known(pc.x, sp.w, y), div_known(pc.y, sp.w, y), div_known(pc.z, sp.w, y));
+            else
+                on = mk(pc.x / sp.w, pc.y / sp.w, pc.z / sp.w);
+        }
         const bool front = dot3(d, on) < 0.0f;
         const V3 n = front ? on : neg(on);
-        V3 smp = mk(0.0f, 0.0f, 0.0f);
-        if (cls != CL_DIEL) { smp.x = sample_pm1(g); smp.y = sample_pm1(g); smp.z = sample_pm1(g); }  // the draw step 2 accepted
         V3 dir;
         bool scattered = true;
         if (cls == CL_LAMB) {  // materials.rs:19-35
-            const V3 unit = normalized(smp);
+            const V3 unit = scale_r(smp, inv_len);  // ultraviolet normalized(): each component times 1 / |smp|
             dir = add(n, unit);
             if (fabsf(dir.x) < 1e-8f && fabsf(dir.y) < 1e-8f && fabsf(dir.z) < 1e-8f) dir = n;
         } else if (cls == CL_METAL) {  // materials.rs:44-61

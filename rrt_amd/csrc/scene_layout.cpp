@@ -58,7 +58,7 @@ int build_scene_layout(const rrt_sphere_soa *sp, const rrt_material_soa *mt, con
 
     // ---- spheres ----
     out.sph.resize(ns); out.motion.resize(ns); out.motion_dt.resize(ns); out.sph_info.resize(ns); out.prim_att.resize(ns);
-    bool any_moving = false, uniform = true, bounded = true;
+    bool any_moving = false, uniform = true, bounded = true, radii_normal = true;
     uint32_t ut0 = 0, ut1 = 0;
     for (uint32_t i = 0; i < ns; i++) {
         const uint32_t m = sp->material_id[i];
@@ -72,6 +72,7 @@ int build_scene_layout(const rrt_sphere_soa *sp, const rrt_material_soa *mt, con
         for (int k = 0; k < 3; k++) still = still && f2u(c0[k]) == f2u(c1[k]) && !is_neg_zero(c0[k]);
         for (int k = 0; k < 3; k++) bounded = bounded && std::fabs(c0[k]) <= 0x1p29f && std::fabs(c1[k]) <= 0x1p29f;  // false for NaN
         bounded = bounded && std::fabs(sp->radius[i]) <= 0x1p30f;
+        radii_normal = radii_normal && std::fabs(sp->radius[i]) >= 0x1p-30f && std::fabs(sp->radius[i]) <= 0x1p30f;
         out.sph[i] = Float4{c0[0], c0[1], c0[2], sp->radius[i]};
         out.motion[i] = Float4{c1[0] - c0[0], c1[1] - c0[1], c1[2] - c0[2], sp->time0[i]};
         out.motion_dt[i] = sp->time1[i] - sp->time0[i];
@@ -93,6 +94,7 @@ int build_scene_layout(const rrt_sphere_soa *sp, const rrt_material_soa *mt, con
     if (any_moving) out.flags |= kSceneHasMoving;
     if (any_moving && uniform) out.flags |= kSceneUniformTimes;
     if (bounded && (!any_moving || uniform)) out.flags |= kSceneBounded;
+    if (radii_normal) out.flags |= kSceneRadiiNormal;
 
     // ---- tree validation: every node reachable from the root exactly once, indices in range ----
     std::vector<uint8_t> seen(n_nodes, 0);

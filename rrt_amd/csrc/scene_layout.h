@@ -46,6 +46,8 @@ constexpr uint32_t kSceneUniformTimes = 2u;
 // every centre component (both ends of a moving sphere's way) is at most 2^29 in magnitude and every radius at most 2^30,
 // and spheres that move share one shutter interval
 constexpr uint32_t kSceneBounded = 4u;
+// every radius has a magnitude in [2^-30, 2^30]: the shade kernel may divide by it through its reciprocal
+constexpr uint32_t kSceneRadiiNormal = 8u;
 
 struct Float4 { float x, y, z, w; };
 

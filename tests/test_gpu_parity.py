@@ -263,6 +263,46 @@ def test_custom_scene_general_motion(gpu_ctx):
         assert_same_image(gpu, ref)
 
 
+def test_normal_division_in_and_out_of_the_short_range(gpu_ctx):
+    """The outward normal (p - c) / radius (sphere.rs:88) is divided through the reciprocal of the radius where every
+    operand is in range, and by the division otherwise.  Camera rays that lie in the plane x = 0 hit spheres centred on
+    that plane with p.x - c.x == 0 exactly (out of range: whole waves divide); after the first bounce the rays are
+    general (in range).  A second scene has a radius beyond 2^30, which switches the short route off for the scene."""
+    sp = np.zeros((4, 9), np.float32)
+    sp[0, 0:3] = sp[0, 3:6] = (0.0, 0.0, 0.0)
+    sp[1, 0:3] = sp[1, 3:6] = (0.0, -100.5, 0.0)
+    sp[2, 0:3] = sp[2, 3:6] = (0.0, 0.9, 0.3)
+    sp[3, 0:3] = sp[3, 3:6] = (0.0, -0.25, 1.5)
+    sp[:, 7] = 1.0
+    sp[:, 8] = (0.5, 100.0, -0.3, 0.2)
+    mt = np.array([[0, 0.8, 0.3, 0.3, 0, 0], [0, 0.5, 0.5, 0.5, 0, 0], [2, 1, 1, 1, 0, 1.5], [1, 0.8, 0.8, 0.9, 0.2, 0]], np.float32)
+    mid = np.arange(4, dtype=np.uint32)
+    cam = rrt_amd.Camera()
+    cam.lower_left_corner[:] = (0.0, -0.75, 3.5)
+    cam.horizontal[:] = (0.0, 1.5, 0.0)     # no x component anywhere: every camera ray has direction.x == 0 and origin.x == 0
+    cam.vertical[:] = (0.0, 0.0, 1.0)
+    cam.origin[:] = (0.0, 0.0, 5.0)
+    cam.u[:] = (0.0, 1.0, 0.0)
+    cam.v[:] = (0.0, 0.0, 1.0)
+    cam.lens_radius, cam.time_low, cam.time_scale = 0.0, 0.0, 0.0
+    for big_radius in (False, True):
+        sp2 = sp.copy()
+        if big_radius:
+            sp2[1, 0:3] = sp2[1, 3:6] = (0.0, -2.0e9 - 0.5, 0.0)
+            sp2[1, 8] = 2.0e9
+        osc = OracleScene.from_arrays(sp2, mid, mt, np.zeros((0, 8), np.uint32), cam.as_array())
+        osc.build_bvh(0)
+        _, _, _, nd, _ = scene_arrays_from_oracle(osc)
+        assert bool(rrt_amd.debug_layout(sp2, mid, mt, nd)[2] & 8) == (not big_radius)
+        gpu_ctx.upload_scene(sp2, mid, mt, nd)
+        gpu_ctx.set_camera(cam)
+        nx, ny, ns = 64, 48, 8
+        ref = osc.render(nx, ny, ns, seed=11, threads=8)
+        gpu = gpu_ctx.render(rrt_amd.Context.params(nx, ny, ns, seed=11, count_work=True))
+        assert_same_image(gpu, ref)
+        assert ref[2]["hits_lambertian"] > 1000 and ref[2]["hits_dielectric"] > 50 and ref[2]["hits_metal"] > 50, ref[2]
+
+
 @pytest.mark.parametrize("max_depth", [50, 300])   # 300: beyond what the narrow per-slot state holds, so the wide layout runs on a small scene
 def test_long_paths_between_two_walls(gpu_ctx, max_depth):
     """A narrow gap between two huge diffuse/metal spheres: paths scatter dozens of times before they see the sky, so the

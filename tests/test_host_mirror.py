@@ -148,18 +148,20 @@ def test_exit_links_reproduce_the_stack_order(kind):
         assert int(words[i, 4]) >> 30 == int(mt[mid[obj], 0])
         assert np.array_equal(words[i, 0:3], sp[obj, 0:3].view(np.uint32))
         assert words[i, 3] == np.float32(sp[obj, 8] * sp[obj, 8]).view(np.uint32)
-    assert flags == 4  # nothing moves; bit 2: every centre and radius is small enough for the short division of the sphere test
+    # nothing moves; bit 2: every centre and radius is small enough for the short division of the sphere test; bit 3: every
+    # radius is in [2^-30, 2^30] in magnitude (the shade kernel divides by it through its reciprocal)
+    assert flags == 12
 
 
 def test_layout_flags_moving_scene():
     osc = OracleScene.build(2, 64, 64, seed=0)
     sp, mid, mt, nd, _ = scene_arrays_from_oracle(osc)
     words, root, flags = rrt_amd.debug_layout(sp, mid, mt, nd)
-    assert flags == 7  # has moving spheres, all with the same shutter interval, and bounded (bit 2)
+    assert flags == 15  # has moving spheres, all with the same shutter interval, bounded (bit 2), radii normal (bit 3)
     sp2 = sp.copy()
     k = np.nonzero((sp[:, 0:3] != sp[:, 3:6]).any(axis=1))[0][0]
     sp2[k, 7] = 2.0
-    assert rrt_amd.debug_layout(sp2, mid, mt, nd)[2] == 1  # another shutter interval: not uniform, and then not "bounded" either
+    assert rrt_amd.debug_layout(sp2, mid, mt, nd)[2] == 9  # another shutter interval: not uniform, and then not "bounded" either
     # a centre or a radius out of the short division's range takes bit 2 away and nothing else
     for col, val in [(0, 3.0e9), (5, -1.0e9), (8, 2.0e9), (1, np.nan)]:
         sp3 = sp.copy()
@@ -167,6 +169,11 @@ def test_layout_flags_moving_scene():
         if col < 3:
             sp3[k, col + 3] = val  # keep centre1 - centre0 as it was in kind (the sphere stays a moving one)
         assert rrt_amd.debug_layout(sp3, mid, mt, nd)[2] & 4 == 0
+    # a radius outside [2^-30, 2^30] (or NaN) takes bit 3 away
+    for val in (1.0e-12, -2.0e9, np.nan):
+        sp3 = sp.copy()
+        sp3[k, 8] = val
+        assert rrt_amd.debug_layout(sp3, mid, mt, nd)[2] & 8 == 0
 
 
 def test_scene_validation_errors():

@@ -1,6 +1,6 @@
 // Randomised check on the GPU of a 3-instruction exact division by a divisor whose correctly rounded reciprocal is known:
 //     y = RN(1 / a);  q0 = n * y;  r = fma(-a, q0, n);  q = fma(r, y, q0)          (Markstein's correction step)
-// against the compiler's IEEE division n / a (-fhip-fp32-correctly-rounded-divide-sqrt), for a in [2^-30, 2^30] and
+// against the compiler's IEEE division n / a (-fhip-fp32-correctly-rounded-divide-sqrt), for |a| in [2^-30, 2^30] (either sign) and
 // |n| in [2^-90, 2^90] — the ranges the render kernels guard — with uniformly random significands plus the patterns that
 // stress rounding (all ones, all zeros, single bits, near-ties built from q * a).
 //   hipcc -O3 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt --offload-arch=gfx950 tools/micro/div_exact.hip -o tools/micro/div_exact
@@ -48,10 +48,11 @@ __global__ void k(unsigned long long *stats, uint32_t iters, uint32_t salt) {
             n = __uint_as_float(((uint32_t)en << 23) | mant(g, k1 >> 3));
         }
         if ((k1 >> 9) & 1u) n = -n;
+        const float a_signed = ((k1 >> 10) & 1u) ? -a : a;  // the shade kernel divides by radii, which may be negative
         const float an = fabsf(n);
         if (!(an >= 0x1p-90f && an <= 0x1p90f)) continue;        // outside the guarded range
-        const float y = recip_newton(a);
-        const float want = n / a, got = div_fast(n, a, y);
+        const float y = recip_newton(a_signed);
+        const float want = n / a_signed, got = div_fast(n, a_signed, y);
         done++;
         if (__float_as_uint(want) != __float_as_uint(got)) bad++;
     }
@@ -68,6 +69,6 @@ int main() {
         if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed\n"); return 1; }
     }
     hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
-    printf("%llu divisions checked (a in [2^-30, 2^30], |n| in [2^-90, 2^90]): %llu differ from n / a\n", h[0], h[1]);
+    printf("%llu divisions checked (|a| in [2^-30, 2^30], |n| in [2^-90, 2^90]): %llu differ from n / a\n", h[0], h[1]);
     return h[1] ? 2 : 0;
 }
