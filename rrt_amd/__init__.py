@@ -282,13 +282,15 @@ class Context:
     @staticmethod
     def params(nx: int, ny: int, ns: int, seed: int = 0, max_depth: int = 50, shard_mode: int = SHARD_NONE, rank: int = 0,
                world: int = 1, count_work: bool = False, path_slots: int = 0, batch_samples: int = 0,
-               time_kernels: bool = False, force_hbm_bvh: bool = False, retire_min: int = 0, leaf_min: int = 0) -> RenderParams:
+               time_kernels: bool = False, force_hbm_bvh: bool = False, retire_min: int = 0, leaf_min: int = 0,
+               exit_link_walk: bool = False) -> RenderParams:
         p = RenderParams()
         p.nx, p.ny, p.ns, p.max_depth, p.seed = nx, ny, ns, max_depth, seed
         p.shard_mode, p.shard_rank, p.shard_world = shard_mode, rank, world
         p.count_work, p.path_slots, p.batch_samples = int(count_work), path_slots, batch_samples
         p.reserved[0] = int(time_kernels)  # True/1: every extend launch timed; n: every n-th (n in 1, 2, 4, 8)
-        p.reserved[1] = int(force_hbm_bvh)
+        # bit 0: walk the node array in HBM even if the scene fits in LDS; bit 1: big scenes node by node along the exit links
+        p.reserved[1] = int(force_hbm_bvh) | (2 if exit_link_walk else 0)
         p.reserved[2] = int(retire_min)
         p.reserved[3] = int(leaf_min)
         return p

@@ -105,7 +105,7 @@ struct rrt_ctx {
     hipEvent_t ev_fork = nullptr, ev_join[kMaxParts - 1] = {};
     hipDeviceProp_t prop{};
     // scene
-    DevBuf nodes, small_nodes, top_nodes, sph, motion, motion_dt, sph_info, prim_att;
+    DevBuf nodes, small_nodes, top_nodes, wide, wide_top, sph, motion, motion_dt, sph_info, prim_att;
     SceneDev sd{};
     bool has_scene = false, moving = false;
     uint32_t n_spheres = 0, n_nodes = 0;
@@ -171,7 +171,7 @@ void rrt_destroy(rrt_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (hipStream_t ss : c->side_stream) if (ss) (void)hipStreamSynchronize(ss);
-    for (DevBuf *b : {&c->nodes, &c->small_nodes, &c->top_nodes, &c->sph, &c->motion, &c->motion_dt, &c->sph_info, &c->prim_att,
+    for (DevBuf *b : {&c->nodes, &c->small_nodes, &c->top_nodes, &c->wide, &c->wide_top, &c->sph, &c->motion, &c->motion_dt, &c->sph_info, &c->prim_att,
                       &c->tmp_rgb, &c->tmp_acc, &c->q_org, &c->q_dir, &c->q_time, &c->q_t, &c->q_obj})
         b->release();
     for (DevBuf &b : c->ws) b.release();
@@ -215,6 +215,7 @@ int upload_scene_impl(rrt_ctx *c, const rrt_sphere_soa *sp, const rrt_material_s
     int rc = build_scene_layout(sp, mt, nodes, n_nodes, L, err);
     if (rc != RRT_OK) return fail(rc, err);
     make_top_tree(L);
+    make_wide_nodes(L);
     HIP_TRY(hipSetDevice(c->device));
     c->has_scene = false;
     auto up = [&](DevBuf &b, const void *src, size_t bytes) -> hipError_t {
@@ -225,6 +226,8 @@ int upload_scene_impl(rrt_ctx *c, const rrt_sphere_soa *sp, const rrt_material_s
     HIP_TRY(up(c->nodes, L.nodes.data(), L.nodes.size() * 4));
     HIP_TRY(up(c->small_nodes, L.small_nodes.data(), L.small_nodes.size() * 4));
     HIP_TRY(up(c->top_nodes, L.top_nodes.data(), L.top_nodes.size() * 4));
+    HIP_TRY(up(c->wide, L.wide.data(), L.wide.size() * 4));
+    HIP_TRY(up(c->wide_top, L.wide_top.data(), L.wide_top.size() * 4));
     HIP_TRY(up(c->sph, L.sph.data(), L.sph.size() * sizeof(Float4)));
     HIP_TRY(up(c->motion, L.motion.data(), L.motion.size() * sizeof(Float4)));
     HIP_TRY(up(c->motion_dt, L.motion_dt.data(), L.motion_dt.size() * 4));
@@ -250,6 +253,9 @@ int upload_scene_impl(rrt_ctx *c, const rrt_sphere_soa *sp, const rrt_material_s
     c->sd.n_spheres = L.n_spheres;
     c->sd.top_nodes = L.top_nodes.empty() ? nullptr : c->top_nodes.as<uint4>();
     c->sd.n_top = (uint32_t)(L.top_nodes.size() / kNodeWords);
+    c->sd.wide = L.wide.empty() ? nullptr : c->wide.as<uint4>();
+    c->sd.wide_top = L.wide.empty() ? nullptr : c->wide_top.as<uint4>();
+    for (int k = 0; k < 6; k++) c->sd.root_box[k] = L.root_box[k];
     c->moving = (L.flags & kSceneHasMoving) != 0;
     c->n_spheres = L.n_spheres;
     c->n_nodes = L.n_nodes;
@@ -388,6 +394,10 @@ int render_queued(rrt_ctx *c, const rrt_render_params &P, const RenderTarget &T,
     const uint32_t leaf_min = P.reserved[3] ? std::min<uint32_t>(P.reserved[3], 64u) : 16u;
     SceneDev sd = c->sd;
     if (P.reserved[1] & 1u) sd.small_nodes = nullptr;  // walk the HBM copy of the BVH even if the scene fits in LDS
+    // reserved[1] bit 1: walk big scenes node by node along the exit links instead of two children per record.  The entry
+    // point that allocates nothing does so always: the two-children walk keeps a stack in scratch memory, which the
+    // runtime allocates when such a kernel is first launched.
+    if ((P.reserved[1] & 2u) || no_alloc || std::getenv("RRT_NO_WIDE")) sd.wide = nullptr;
     // reserved[0] = n: HIP events around every n-th extend launch of each part (n divides the rounds of a chunk, so the
     // timed launches are an even 1-in-n sample); the counting build times every launch.  Timing creates events on
     // demand, so the entry point that must not allocate leaves it out.

@@ -263,8 +263,14 @@ typedef const __attribute__((address_space(3))) u32x4 *LdsNodePtr;  // spelled o
 template <class Ptr>
 DEV uint4 load4(Ptr p, uint32_t i) { const u32x4 v = p[i]; return make_uint4(v.x, v.y, v.z, v.w); }
 
+struct NoStack {};  // the walks along exit links keep nothing but the current node
+DEV void bind_spill(NoStack &, uint2 *) {}
+
 template <bool MOVING, class TopPtr = HbmNodePtr>
 struct HbmStore {
+    typedef NoStack Stack;
+    static constexpr bool kCountsItself = false;
+    static constexpr uint32_t kSpillEntries = 1;
     const SceneDev &S;
     TopPtr top;  // the copy of the top of the tree that references with kRefTopBit index: in HBM, or (k_extend_top) in LDS
     DEV explicit HbmStore(const SceneDev &s) : S(s), top(reinterpret_cast<HbmNodePtr>(s.top_nodes)) {}
@@ -285,6 +291,7 @@ struct HbmStore {
         }
     }
     DEV bool uniform_times() const { return MOVING && (S.flags & kSceneUniformTimes); }
+    DEV uint32_t start(RayCtx &, NoStack &, uint32_t &) const { return root(); }
     // bx, by, bz: per axis the (near, far) planes of the node's box for this ray (acceleration.rs:66-71)
     DEV void inner(uint32_t cur, const RayCtx &r, f32x2 &bx, f32x2 &by, f32x2 &bz, uint32_t &near_ref, uint32_t &exit_ref) const {
         const uint32_t oct = r.oct;
@@ -317,11 +324,15 @@ struct HbmStore {
 // The compact image in LDS (scene_layout.h): a reference is a node's LDS address, inner nodes lie below `end`, leaves above.
 template <bool MOVING>
 struct LdsStore {
+    typedef NoStack Stack;
+    static constexpr bool kCountsItself = false;
+    static constexpr uint32_t kSpillEntries = 1;
     uint32_t root16, end16;
     DEV LdsStore(uint32_t root, uint32_t end) : root16(root), end16(end) {}
     DEV uint32_t root() const { return root16; }
     DEV uint32_t end() const { return end16; }
     DEV bool uniform_times() const { return MOVING; }  // the compact copy exists only for scenes with one shutter interval
+    DEV uint32_t start(RayCtx &, NoStack &, uint32_t &) const { return root(); }
     typedef const __attribute__((address_space(3))) uint32_t *LdsWordPtr;
     typedef const __attribute__((address_space(3))) float *LdsFloatPtr;
     typedef const __attribute__((address_space(3))) uint16_t *LdsHalfPtr;
@@ -379,7 +390,7 @@ DEV void slab_interval(f32x2 bx, f32x2 by, f32x2 bz, const RayCtx &r, float &t0,
 }
 
 template <bool MOVING, class TopPtr>
-DEV uint32_t visit_inner(const HbmStore<MOVING, TopPtr> &st, uint32_t cur, const RayCtx &r) {
+DEV uint32_t visit_inner(const HbmStore<MOVING, TopPtr> &st, uint32_t cur, RayCtx &r, NoStack &, bool, uint32_t &, uint32_t &) {
     f32x2 bx, by, bz;
     uint32_t near_ref, exit_ref;
     st.inner(cur, r, bx, by, bz, near_ref, exit_ref);
@@ -389,7 +400,7 @@ DEV uint32_t visit_inner(const HbmStore<MOVING, TopPtr> &st, uint32_t cur, const
 }
 
 template <bool MOVING>
-DEV uint32_t visit_inner(const LdsStore<MOVING> &st, uint32_t cur, const RayCtx &r) {
+DEV uint32_t visit_inner(const LdsStore<MOVING> &st, uint32_t cur, RayCtx &r, NoStack &, bool, uint32_t &, uint32_t &) {
     f32x2 bx, by, bz;
     uint32_t links;
     st.inner(cur, r, bx, by, bz, links);
@@ -405,12 +416,7 @@ DEV uint32_t visit_inner(const LdsStore<MOVING> &st, uint32_t cur, const RayCtx 
 // Sphere::hit (sphere.rs:68-85); the Hit record itself is rebuilt in shade, for the final hit only.  (Deferring the
 // square root and divisions until many lanes need them was tried: lanes that wait for roots cost the descent passes as
 // many idle lanes as the batched root passes save.)
-template <class Store>
-DEV uint32_t visit_leaf(const Store &st, uint32_t cur, RayCtx &r, bool quick) {  // quick: wave-uniform, every ray of the wave passes quick_div_ok
-    V3 c;
-    float rr;
-    uint32_t handle, exit_ref;
-    st.leaf(cur, r, c, rr, handle, exit_ref);
+DEV void sphere_test(V3 c, float rr, uint32_t handle, RayCtx &r, bool quick) {  // quick: wave-uniform, every ray of the wave passes quick_div_ok
     const V3 oc = sub(origin(r), c);
     const float half_b = dot3(oc, r.d);
     const float cc = dot3(oc, oc) - rr;
@@ -425,7 +431,165 @@ DEV uint32_t visit_leaf(const Store &st, uint32_t cur, RayCtx &r, bool quick) { 
         }
         if (!outside) { r.tmax = root; r.best = handle; }
     }
+}
+
+template <class Store>
+DEV uint32_t visit_leaf(const Store &st, uint32_t cur, RayCtx &r, NoStack &, bool quick, uint32_t &, uint32_t &) {
+    V3 c;
+    float rr;
+    uint32_t handle, exit_ref;
+    st.leaf(cur, r, c, rr, handle, exit_ref);
+    sphere_test(c, rr, handle, r, quick);
     return exit_ref;
+}
+
+// ---- The two-children walk of scenes whose nodes stay in HBM ----
+//
+// A pass of the walk along exit links costs one dependent memory round trip per node, and a wave waits for the slowest
+// of its 64 lanes: with a few hundred thousand nodes in play nearly every pass waits for a miss.  Here a record holds what
+// the walk needs of BOTH children of an inner node (their boxes; for a leaf child its sphere), so a round trip settles two
+// nodes, and a leaf reached from its parent costs none.  The order of acceleration.rs:236-267 is kept exactly: the near
+// child is dealt with at once; the far child waits on a stack (the reference's) unless the near child turns out to be a
+// miss or a leaf, in which case the far child is next anyway and is dealt with in the same visit.  The reference tests a
+// waiting child's box when it pops it, against the closest hit so far; the entry distance t0 and the scaled exit
+// distance do not depend on that, so the box is worked out when the record is at hand, the child is dropped if it misses
+// even the current t_max (t_max only shrinks), and otherwise waits with its t0: popping it is `t0 <= t_max`.
+// The newest two waiting children live in registers, older ones in scratch memory: scratch goes through the same
+// address path as the record gathers, which is what bounds this walk, and a ray seldom has more than a few waiting.
+constexpr uint32_t kWideStack = kWideStackDepth;
+struct WideStack {
+    uint2 r0, r1;          // {reference, t0 bits}, r0 the newest
+    uint32_t nr;           // how many of them are valid
+    uint2 *e;              // the older ones, oldest first: an array of kWideStack entries of the caller's (kept apart from the
+    uint32_t n;            // members above so that those stay in registers)
+    DEV void clear() { nr = 0u; n = 0u; r0 = r1 = make_uint2(kRefEnd, 0u); }
+    DEV bool empty() const { return nr == 0u && n == 0u; }
+    DEV void push(uint2 v) {
+        if (nr == 2u) e[n++] = r1;
+        r1 = r0; r0 = v;
+        nr = min(nr + 1u, 2u);
+    }
+    DEV uint2 pop() {  // not empty
+        uint2 v;
+        if (nr != 0u) { v = r0; r0 = r1; nr -= 1u; }
+        else v = e[--n];
+        return v;
+    }
+};
+DEV void bind_spill(WideStack &k, uint2 *e) { k.e = e; }
+
+template <bool MOVING, bool COUNT>
+struct WideStore {
+    typedef WideStack Stack;
+    static constexpr bool kCountsItself = true;
+    static constexpr uint32_t kSpillEntries = kWideStack;
+    const SceneDev &S;
+    LdsNodePtr top;  // LDS copy of the records of the top of the tree
+    DEV WideStore(const SceneDev &s, LdsNodePtr top_copy) : S(s), top(top_copy) {}
+    DEV uint32_t end() const { return kRefEnd; }
+    DEV bool uniform_times() const { return MOVING && (S.flags & kSceneUniformTimes); }
+    DEV void prepare(RayCtx &) const {}
+    DEV uint32_t prim_of(uint32_t handle) const { return handle; }
+    // (near, far) planes of a box given as (min, max) pairs, for this ray (acceleration.rs:66-71)
+    DEV static void box_test(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t w4, uint32_t w5, const RayCtx &r, float &t0, float &t1) {
+        const bool ngx = r.oct & 1u, ngy = r.oct & 2u, ngz = r.oct & 4u;
+        const f32x2 bx = ngx ? f32x2{u2f(w1), u2f(w0)} : f32x2{u2f(w0), u2f(w1)};
+        const f32x2 by = ngy ? f32x2{u2f(w3), u2f(w2)} : f32x2{u2f(w2), u2f(w3)};
+        const f32x2 bz = ngz ? f32x2{u2f(w5), u2f(w4)} : f32x2{u2f(w4), u2f(w5)};
+        slab_interval(bx, by, bz, r, t0, t1);
+    }
+    // a leaf's six words: centre at time0, radius^2, sphere word, moving flag
+    DEV void leaf_test(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t w4, uint32_t w5, RayCtx &r, bool quick) const {
+        V3 c = mk(u2f(w0), u2f(w1), u2f(w2));
+        if (MOVING && (w5 & 1u)) {  // center_at (sphere.rs:61-64)
+            const uint32_t prim = w4 & kLeafPrimMask;
+            const float4 m = S.motion[prim];
+            const float f = (S.flags & kSceneUniformTimes) ? r.f_ray : (r.time - m.w) / S.motion_dt[prim];
+            c = add(c, scale(f, mk(m.x, m.y, m.z)));
+        }
+        sphere_test(c, u2f(w3), w4, r, quick);
+    }
+    // The next node of the walk once everything at hand is done: the newest waiting child that still passes.  A waiting
+    // inner child counts as a box test here, when the reference would pop and test it.
+    DEV uint32_t pop(RayCtx &r, WideStack &k, uint32_t &n_inner) const {
+        while (!k.empty()) {
+            const uint2 e = k.pop();
+            if (e.x & kRefLeafBit) return e.x;
+            if (COUNT) n_inner++;
+            if (u2f(e.y) <= r.tmax) return e.x;
+        }
+        return kRefEnd;
+    }
+    // Bvh::hit's first pop (acceleration.rs:236): the root, whose box no record holds
+    DEV uint32_t start(RayCtx &r, WideStack &k, uint32_t &n_inner) const {
+        k.clear();
+        if (S.root_ref & kRefLeafBit) return S.root_ref;
+        float t0, t1;
+        box_test(f2u(S.root_box[0]), f2u(S.root_box[1]), f2u(S.root_box[2]), f2u(S.root_box[3]), f2u(S.root_box[4]), f2u(S.root_box[5]), r, t0, t1);
+        if (COUNT) n_inner++;
+        return t0 <= t1 ? S.root_ref : kRefEnd;
+    }
+};
+
+// `cur` is an inner node whose box the ray is known to hit: deal with its two children.
+template <bool MOVING, bool COUNT>
+DEV uint32_t visit_inner(const WideStore<MOVING, COUNT> &st, uint32_t cur, RayCtx &r, WideStack &k, bool quick, uint32_t &n_inner, uint32_t &n_leaf) {
+    const uint32_t idx = cur & kRefIndexMask;
+    uint4 q0, q1, q2, q3;
+    if (cur & kRefTopBit) { q0 = load4(st.top, idx * 4u); q1 = load4(st.top, idx * 4u + 1u); q2 = load4(st.top, idx * 4u + 2u); q3 = load4(st.top, idx * 4u + 3u); }
+    else { q0 = st.S.wide[idx * 4u]; q1 = st.S.wide[idx * 4u + 1u]; q2 = st.S.wide[idx * 4u + 2u]; q3 = st.S.wide[idx * 4u + 3u]; }
+    const uint32_t left = q3.x, right = q3.y & kRefMask;
+    const uint32_t axis = (q3.y >> RRT_NODE_AXIS_SHIFT) & 3u;
+    const bool right_first = ((r.oct >> axis) & 1u) != 0u;  // acceleration.rs:253-267
+    const uint32_t near_ref = right_first ? right : left, far_ref = right_first ? left : right;
+    // the six words of the near and of the far child
+    const uint32_t n0 = right_first ? q1.z : q0.x, n1 = right_first ? q1.w : q0.y, n2 = right_first ? q2.x : q0.z;
+    const uint32_t n3 = right_first ? q2.y : q0.w, n4 = right_first ? q2.z : q1.x, n5 = right_first ? q2.w : q1.y;
+    const uint32_t f0 = right_first ? q0.x : q1.z, f1 = right_first ? q0.y : q1.w, f2 = right_first ? q0.z : q2.x;
+    const uint32_t f3 = right_first ? q0.w : q2.y, f4 = right_first ? q1.x : q2.z, f5 = right_first ? q1.y : q2.w;
+    bool enter_near = false;
+    if (near_ref & kRefLeafBit) {
+        if (COUNT) n_leaf++;
+        st.leaf_test(n0, n1, n2, n3, n4, n5, r, quick);
+    } else {
+        float t0, t1;
+        st.box_test(n0, n1, n2, n3, n4, n5, r, t0, t1);
+        if (COUNT) n_inner++;
+        enter_near = t0 <= t1;
+    }
+    if (enter_near) {  // the far child waits for the near child's subtree
+        if (far_ref & kRefLeafBit) {
+            k.push(make_uint2(far_ref, 0u));
+        } else {
+            float t0, t1;
+            st.box_test(f0, f1, f2, f3, f4, f5, r, t0, t1);
+            if (t0 <= t1) k.push(make_uint2(far_ref, f2u(t0)));
+            else if (COUNT) n_inner++;  // the reference pops it later and it misses then too
+        }
+        return near_ref;
+    }
+    // the near child is done with (a miss, or a sphere): the far child is the next pop
+    if (far_ref & kRefLeafBit) {
+        if (COUNT) n_leaf++;
+        st.leaf_test(f0, f1, f2, f3, f4, f5, r, quick);
+        return st.pop(r, k, n_inner);
+    }
+    float t0, t1;
+    st.box_test(f0, f1, f2, f3, f4, f5, r, t0, t1);
+    if (COUNT) n_inner++;
+    if (t0 <= t1) return far_ref;
+    return st.pop(r, k, n_inner);
+}
+
+// a leaf that waited on the stack (or the root of a one-sphere scene): its words come from its own node
+template <bool MOVING, bool COUNT>
+DEV uint32_t visit_leaf(const WideStore<MOVING, COUNT> &st, uint32_t cur, RayCtx &r, WideStack &k, bool quick, uint32_t &n_inner, uint32_t &n_leaf) {
+    const uint32_t idx = cur & kRefIndexMask;
+    const uint4 *src = (cur & kRefTopBit) ? st.S.top_nodes : st.S.nodes;
+    const uint4 a = src[idx * 4u], b = src[idx * 4u + 1u];
+    if (COUNT) n_leaf++;
+    st.leaf_test(a.x, a.y, a.z, a.w, b.x, b.y, r, quick);
+    return st.pop(r, k, n_inner);
 }
 
 DEV uint64_t wave_sum_u64(uint64_t v) {
@@ -467,6 +631,9 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
     uint32_t head = 0;  // first list position not handed out yet (wave-uniform)
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     RayCtx r;
+    typename Store::Stack stk;
+    uint2 stack_spill[Store::kSpillEntries];
+    bind_spill(stk, stack_spill);
     ray_load(r, make_float4(0, 0, 0, 0), make_float4(1, 1, 1, 0), make_float4(1, 1, 1, 3), 0.001f, __FLT_MAX__, S, false);
     uint32_t cur = kEnd;
     const bool may_quick = (S.flags & kSceneBounded) != 0u && P.t_min >= 0x1p-40f;
@@ -504,7 +671,7 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
                 const float4 nC = ray_constants(mk(nB.x, nB.y, nB.z));  // 1/d and d.d, once per ray (types.rs:21-23, sphere.rs:71)
                 ray_load(r, nA, nB, nC, P.t_min, P.t_max, S, uniform_times);  // lib.rs:57
                 st.prepare(r);
-                cur = st.root();
+                cur = st.start(r, stk, n_inner);
                 has = true;
             }
             quick = may_quick && __ballot(has && !quick_div_ok<MOVING>(r)) == 0ull;
@@ -519,23 +686,23 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
             if (im == 0ull) break;
             if (COUNT) { d_desc_iters++; d_desc_lanes += (uint32_t)__popcll(im); }
             if (at_inner) {
-                if (COUNT) n_inner++;
-                cur = visit_inner(st, cur, r);
+                if (COUNT && !Store::kCountsItself) n_inner++;
+                cur = visit_inner(st, cur, r, stk, quick, n_inner, n_leaf);
             }
             at_inner = cur < kEnd;
             im = __ballot(at_inner);
             if (im == 0ull) break;
             if (COUNT) { d_desc_iters++; d_desc_lanes += (uint32_t)__popcll(im); }
             if (at_inner) {
-                if (COUNT) n_inner++;
-                cur = visit_inner(st, cur, r);
+                if (COUNT && !Store::kCountsItself) n_inner++;
+                cur = visit_inner(st, cur, r, stk, quick, n_inner, n_leaf);
             }
             if ((uint32_t)__popcll(__ballot(cur > kEnd)) >= leaf_min) break;
         }
         if (COUNT) { const uint64_t lm = __ballot(cur > kEnd); if (lm) { d_leaf_iters++; d_leaf_lanes += (uint32_t)__popcll(lm); } }
         if (cur > kEnd) {
-            if (COUNT) n_leaf++;
-            cur = visit_leaf(st, cur, r, quick);
+            if (COUNT && !Store::kCountsItself) n_leaf++;
+            cur = visit_leaf(st, cur, r, stk, quick, n_inner, n_leaf);
         }
     }
     uint64_t *stt = wave_stats + (size_t)wave * kWaveStatWords;
@@ -649,6 +816,30 @@ __global__ __launch_bounds__(kLdsBlockThreads, 8) void k_extend_top(SceneDev S, 
     const HbmStore<MOVING, LdsNodePtr> st(S, (LdsNodePtr)lds4);
     extend_wave<HbmStore<MOVING, LdsNodePtr>, MOVING, COUNT>(st, S, P, wave, lane, retire_min, leaf_min, wave_stats, own_count, pooled ? &pool[0] : nullptr,
                                                  wave0 * kWaveSlots, total);
+}
+
+// The same with the two-children records (WideStore): the records of the top levels are walked in an LDS copy.
+template <bool MOVING, bool COUNT>
+__global__ __launch_bounds__(kLdsBlockThreads, 8) void k_extend_wide(SceneDev S, PathState P, uint32_t retire_min, uint32_t leaf_min,
+                                                                   uint64_t *wave_stats) {
+    extern __shared__ uint4 lds4[];
+    __shared__ uint32_t pool[2];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave0 = P.wave_begin + blockIdx.x * (kLdsBlockThreads / 64u);
+    const uint32_t wave = wave0 + (threadIdx.x >> 6);
+    const uint32_t own_count = wave < P.wave_end ? rfl(P.qcount[wave]) : 0u;
+    if (threadIdx.x < 2) pool[threadIdx.x] = 0u;
+    for (uint32_t i = threadIdx.x; i < S.n_top * 4u; i += kLdsBlockThreads) lds4[i] = S.wide_top[i];
+    __syncthreads();
+    if (lane == 0 && own_count) atomicAdd(&pool[1], own_count);
+    __syncthreads();
+    if (wave >= P.wave_end) return;
+    const uint32_t n_lists = min(kLdsBlockThreads / 64u, P.wave_end - wave0);
+    const uint32_t total = rfl(pool[1]);
+    const bool pooled = total == n_lists * kWaveSlots;
+    const WideStore<MOVING, COUNT> st(S, (LdsNodePtr)lds4);
+    extend_wave<WideStore<MOVING, COUNT>, MOVING, COUNT>(st, S, P, wave, lane, retire_min, leaf_min, wave_stats, own_count, pooled ? &pool[0] : nullptr,
+                                                        wave0 * kWaveSlots, total);
 }
 
 // (1 - cos)^5 of materials.rs:68, as a double-precision product rounded once to f32
@@ -1392,6 +1583,19 @@ void launch_extend(hipStream_t s, const SceneDev &S, const PathState &P, bool mo
         } else {
             if (count) hipLaunchKernelGGL((k_count_extend_lds<false>), g, b, lds, s, S, P, retire_min, leaf_min, wave_stats);
             else hipLaunchKernelGGL((k_extend_lds<false, false>), g, b, lds, s, S, P, retire_min, leaf_min, wave_stats);
+        }
+        return;
+    }
+    if (S.top_nodes && S.n_top && S.wide) {
+        const uint32_t waves_per_block = kLdsBlockThreads / 64u;
+        const dim3 g((P.wave_end - P.wave_begin + waves_per_block - 1u) / waves_per_block), b(kLdsBlockThreads);
+        const size_t lds = (size_t)S.n_top * kNodeWords * 4u;
+        if (moving) {
+            if (count) hipLaunchKernelGGL((k_extend_wide<true, true>), g, b, lds, s, S, P, retire_min, leaf_min, wave_stats);
+            else hipLaunchKernelGGL((k_extend_wide<true, false>), g, b, lds, s, S, P, retire_min, leaf_min, wave_stats);
+        } else {
+            if (count) hipLaunchKernelGGL((k_extend_wide<false, true>), g, b, lds, s, S, P, retire_min, leaf_min, wave_stats);
+            else hipLaunchKernelGGL((k_extend_wide<false, false>), g, b, lds, s, S, P, retire_min, leaf_min, wave_stats);
         }
         return;
     }

@@ -278,4 +278,34 @@ void make_top_tree(SceneLayout &L) {
         for (uint32_t j = 0; j < kNodeWords; j++) L.top_nodes[k * kNodeWords + j] = L.nodes[static_cast<size_t>(order[k]) * kNodeWords + j];
 }
 
+void make_wide_nodes(SceneLayout &L) {
+    L.wide.clear(); L.wide_top.clear();
+    if (L.top_nodes.empty() || L.root_ref == kRefEnd || L.max_leaf_depth >= kWideStackDepth) return;
+    auto node_words = [&](uint32_t ref) -> const uint32_t * {
+        const size_t idx = ref & kRefIndexMask;
+        return (ref & kRefTopBit) ? &L.top_nodes[idx * kNodeWords] : &L.nodes[idx * kNodeWords];
+    };
+    auto fill = [&](const uint32_t *w, uint32_t *rec) {  // w: an inner node's words, references already final
+        const uint32_t left = w[7], right = w[6] & kRefMask;
+        const uint32_t *lw = node_words(left), *rw = node_words(right);
+        for (int k = 0; k < 6; k++) { rec[k] = lw[k]; rec[6 + k] = rw[k]; }
+        rec[12] = left; rec[13] = w[6];
+        rec[14] = rec[15] = 0u;
+    };
+    L.wide.assign(static_cast<size_t>(L.n_nodes) * kNodeWords, 0u);
+    parallel_ranges(L.n_nodes, [&](size_t begin, size_t end) {
+        for (size_t i = begin; i < end; i++)
+            if (L.node_kind[i] == 1) fill(&L.nodes[i * kNodeWords], &L.wide[i * kNodeWords]);
+    });
+    const size_t n_top = L.top_nodes.size() / kNodeWords;
+    L.wide_top.assign(n_top * kNodeWords, 0u);
+    for (size_t k = 0; k < n_top; k++) {
+        const uint32_t *w = &L.top_nodes[k * kNodeWords];
+        // an inner node's child references are never zero (node 0 is the root, nobody's child); a leaf's words 6 and 7 are
+        if (w[6] != 0u || w[7] != 0u) fill(w, &L.wide_top[k * kNodeWords]);
+    }
+    const uint32_t *rw = node_words(L.root_ref);
+    for (int k = 0; k < 6; k++) { uint32_t u = rw[k]; std::memcpy(&L.root_box[k], &u, 4); }
+}
+
 }  // namespace rrt_amd

@@ -78,6 +78,14 @@ struct SceneLayout {
     // whose nodes stay in HBM: the extend kernel keeps this copy in LDS.  Filled by make_top_tree.
     std::vector<uint32_t> top_nodes;
 
+    // Records of the two-children walk of big scenes (filled by make_wide_nodes, after make_top_tree; empty if the tree is
+    // deeper than the walk's stack): one 64-byte record per inner node, indexed like `nodes` (`wide`) and like `top_nodes`
+    // (`wide_top`).  Words [0..5] describe the left child and [6..11] the right child: an inner child's box as (min, max)
+    // per axis, a leaf child's sphere as in a leaf node (centre at time0, radius^2, sphere word, moving flag);
+    // [12] left reference, [13] right reference | axis << 29.  `root_box`: the root's own box (no record holds it).
+    std::vector<uint32_t> wide, wide_top;
+    float root_box[6] = {0, 0, 0, 0, 0, 0};
+
     std::vector<Float4> sph;        // {centre at time0, radius}
     std::vector<Float4> motion;     // {centre1 - centre0, time0}
     std::vector<float> motion_dt;   // time1 - time0
@@ -92,6 +100,10 @@ struct SceneLayout {
 // For a layout without a compact copy: picks the top levels of the tree, copies their nodes to `top_nodes` and rewrites
 // every reference to one of them, in `nodes`, `top_nodes` and `root_ref`, as kRefTopBit | index in `top_nodes`.
 void make_top_tree(SceneLayout &layout);
+
+// Builds `wide`, `wide_top` and `root_box` from `nodes` / `top_nodes` (call after make_top_tree).
+constexpr uint32_t kWideStackDepth = 64;  // deferred children a ray can hold: one per level of the tree at most
+void make_wide_nodes(SceneLayout &layout);
 
 // Returns RRT_OK or a negative rrt_status with a message in err.
 int build_scene_layout(const rrt_sphere_soa *spheres, const rrt_material_soa *materials, const rrt_bvh_node *nodes,

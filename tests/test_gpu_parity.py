@@ -500,9 +500,13 @@ def test_large_scene_walks_the_hbm_bvh(gpu_ctx):
     gpu_ctx.upload_host_scene(hs)
     osc = OracleScene.build(rrt_amd.SCENE_RANDOM_SPHERES, nx, ny, seed=0, half=half)
     ref = osc.render(nx, ny, ns, seed=6, threads=8)
-    gpu = gpu_ctx.render(rrt_amd.Context.params(nx, ny, ns, seed=6, count_work=True))
-    assert_same_image(gpu, ref)
-    assert gpu[2]["inner_visits"] == ref[2]["inner_visits"] and gpu[2]["leaf_tests"] == ref[2]["leaf_tests"]
+    # both walks of a big scene: two children per record (the default) and node by node along the exit links (what the
+    # entry point that allocates nothing runs); with and without the work counters (different kernels)
+    for exit_links in (False, True):
+        gpu = gpu_ctx.render(rrt_amd.Context.params(nx, ny, ns, seed=6, count_work=True, exit_link_walk=exit_links))
+        assert_same_image(gpu, ref)
+        assert gpu[2]["inner_visits"] == ref[2]["inner_visits"] and gpu[2]["leaf_tests"] == ref[2]["leaf_tests"]
+        assert_same_image(gpu_ctx.render(rrt_amd.Context.params(nx, ny, ns, seed=6, exit_link_walk=exit_links)), ref)
     # Bvh::hit alone on the same scene: the walk starts in the copy of the top of the tree and continues in the node array
     idx = np.arange(nx * ny, dtype=np.uint32)
     rays, _ = osc.gen_primary(nx, ny, 11, idx, np.zeros(nx * ny, np.uint32))
@@ -510,6 +514,38 @@ def test_large_scene_walks_the_hbm_bvh(gpu_ctx):
     t_g, obj_g = gpu_ctx.intersect(rays[:, 0:3], rays[:, 3:6], rays[:, 6])
     assert np.array_equal(obj_g, obj_o) and np.array_equal(bits(t_g), bits(t_o))
     assert (obj_o != 0xFFFFFFFF).sum() > 100
+
+
+@pytest.mark.parametrize("uniform_times", [True, False])
+def test_large_scene_with_moving_spheres(gpu_ctx, uniform_times):
+    """14 k spheres, half of them moving (one shutter interval for all, or per-sphere intervals): both walks of a big scene
+    in their moving-sphere variants, against the oracle."""
+    nx, ny, ns, half = 80, 48, 4, 60
+    base = OracleScene.build(rrt_amd.SCENE_RANDOM_SPHERES, nx, ny, seed=0, half=half)
+    sp, mid, mt, _, cam21 = scene_arrays_from_oracle(base)
+    rng = np.random.default_rng(5)
+    sp = sp.copy()
+    n = sp.shape[0]
+    move = rng.uniform(size=n) < 0.5
+    move[0] = False  # the ground
+    sp[move, 4] = sp[move, 1] + rng.uniform(0.0, 0.5, int(move.sum())).astype(np.float32)
+    if not uniform_times:
+        sp[move, 6] = rng.choice([0.0, 0.25], int(move.sum())).astype(np.float32)
+        sp[move, 7] = rng.choice([1.0, 0.75, 2.0], int(move.sum())).astype(np.float32)
+    cam = rrt_amd.Camera.from_buffer_copy(cam21.tobytes())
+    cam.time_low, cam.time_scale = 0.0, float(np.float32(1.0) / np.float32(1.0 - 2.0 ** -23))
+    osc = OracleScene.from_arrays(sp, mid, mt, np.zeros((0, 8), np.uint32), cam.as_array())
+    osc.build_bvh(0)
+    _, _, _, nd, _ = scene_arrays_from_oracle(osc)
+    assert nd.shape[0] * 64 > 64 * 1024
+    gpu_ctx.upload_scene(sp, mid, mt, nd)
+    gpu_ctx.set_camera(cam)
+    ref = osc.render(nx, ny, ns, seed=9, threads=8)
+    for exit_links in (False, True):
+        gpu = gpu_ctx.render(rrt_amd.Context.params(nx, ny, ns, seed=9, count_work=True, exit_link_walk=exit_links))
+        assert_same_image(gpu, ref)
+        assert gpu[2]["inner_visits"] == ref[2]["inner_visits"] and gpu[2]["leaf_tests"] == ref[2]["leaf_tests"]
+        assert_same_image(gpu_ctx.render(rrt_amd.Context.params(nx, ny, ns, seed=9, exit_link_walk=exit_links)), ref)
 
 
 def test_million_sphere_scene_spot(gpu_ctx):
