@@ -263,6 +263,8 @@ typedef const __attribute__((address_space(3))) u32x4 *LdsNodePtr;  // spelled o
 template <class Ptr>
 DEV uint4 load4(Ptr p, uint32_t i) { const u32x4 v = p[i]; return make_uint4(v.x, v.y, v.z, v.w); }
 
+constexpr uint32_t kLdsBlockThreads = 1024;  // 16 waves share one LDS copy of the scene (or of the top of its tree)
+
 struct NoStack {};  // the walks along exit links keep nothing but the current node
 DEV void bind_spill(NoStack &, uint2 *) {}
 
@@ -372,6 +374,16 @@ DEV f32x2 slab_pair(f32x2 box, f32x2 oi) {
     return t;
 }
 
+// The same without the last step: t0 as below, f the scaled exit distance before it is limited by t_max
+DEV void slab_entry_exit(f32x2 bx, f32x2 by, f32x2 bz, const RayCtx &r, float &t0, float &f) {
+    const f32x2 tx = slab_pair(bx, r.ox), ty = slab_pair(by, r.oy), tz = slab_pair(bz, r.oz);
+    float n3, f3;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(n3) : "v"(tx.x), "v"(ty.x), "v"(tz.x));
+    asm("v_max_f32 %0, %1, %2" : "=v"(t0) : "v"(n3), "v"(r.tmin));
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(f3) : "v"(tx.y), "v"(ty.y), "v"(tz.y));
+    f = f3 * RRT_FAR_SCALE;
+}
+
 // t0 <= t1 of the slab test, from the three (near, far) plane pairs
 DEV void slab_interval(f32x2 bx, f32x2 by, f32x2 bz, const RayCtx &r, float &t0, float &t1) {
     const f32x2 tx = slab_pair(bx, r.ox), ty = slab_pair(by, r.oy), tz = slab_pair(bz, r.oz);
@@ -454,26 +466,29 @@ DEV uint32_t visit_leaf(const Store &st, uint32_t cur, RayCtx &r, NoStack &, boo
 // waiting child's box when it pops it, against the closest hit so far; the entry distance t0 and the scaled exit
 // distance do not depend on that, so the box is worked out when the record is at hand, the child is dropped if it misses
 // even the current t_max (t_max only shrinks), and otherwise waits with its t0: popping it is `t0 <= t_max`.
-// The newest two waiting children live in registers, older ones in scratch memory: scratch goes through the same
-// address path as the record gathers, which is what bounds this walk, and a ray seldom has more than a few waiting.
+// Waiting children are kept by their position on the stack: the first kWideLdsEntries positions in LDS (entry k of the
+// workgroup's lane l at (k * 1024 + l) * 8, no bank conflicts), deeper ones in scratch memory.  Scratch goes through the
+// same address path as the record gathers, which is what bounds this walk (a first version with the whole stack in
+// scratch was no faster than the walk along exit links), and a ray seldom has more than a few children waiting.
 constexpr uint32_t kWideStack = kWideStackDepth;
+constexpr uint32_t kWideLdsEntries = 6;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) u32x2 *LdsStackPtr;
 struct WideStack {
-    uint2 r0, r1;          // {reference, t0 bits}, r0 the newest
-    uint32_t nr;           // how many of them are valid
-    uint2 *e;              // the older ones, oldest first: an array of kWideStack entries of the caller's (kept apart from the
-    uint32_t n;            // members above so that those stay in registers)
-    DEV void clear() { nr = 0u; n = 0u; r0 = r1 = make_uint2(kRefEnd, 0u); }
-    DEV bool empty() const { return nr == 0u && n == 0u; }
+    LdsStackPtr l;  // this lane's entry 0 in LDS; entry k is kLdsBlockThreads entries further on
+    uint2 *e;       // positions from kWideLdsEntries on: an array of the caller's
+    uint32_t n;
+    DEV void clear() { n = 0u; }
+    DEV bool empty() const { return n == 0u; }
     DEV void push(uint2 v) {
-        if (nr == 2u) e[n++] = r1;
-        r1 = r0; r0 = v;
-        nr = min(nr + 1u, 2u);
+        if (n < kWideLdsEntries) l[n * kLdsBlockThreads] = u32x2{v.x, v.y};
+        else e[n - kWideLdsEntries] = v;
+        n += 1u;
     }
     DEV uint2 pop() {  // not empty
-        uint2 v;
-        if (nr != 0u) { v = r0; r0 = r1; nr -= 1u; }
-        else v = e[--n];
-        return v;
+        n -= 1u;
+        if (n < kWideLdsEntries) { const u32x2 v = l[n * kLdsBlockThreads]; return make_uint2(v.x, v.y); }
+        return e[n - kWideLdsEntries];
     }
 };
 DEV void bind_spill(WideStack &k, uint2 *e) { k.e = e; }
@@ -482,21 +497,25 @@ template <bool MOVING, bool COUNT>
 struct WideStore {
     typedef WideStack Stack;
     static constexpr bool kCountsItself = true;
-    static constexpr uint32_t kSpillEntries = kWideStack;
+    static constexpr uint32_t kSpillEntries = kWideStack - kWideLdsEntries;
     const SceneDev &S;
-    LdsNodePtr top;  // LDS copy of the records of the top of the tree
-    DEV WideStore(const SceneDev &s, LdsNodePtr top_copy) : S(s), top(top_copy) {}
+    LdsNodePtr top;      // LDS copy of the first `n_top_lds` records of the top of the tree
+    uint32_t n_top_lds;
+    LdsStackPtr stack0;  // entry 0 of this lane's stack in LDS
+    DEV WideStore(const SceneDev &s, LdsNodePtr top_copy, uint32_t n_top_copy, LdsStackPtr lane_stack) : S(s), top(top_copy), n_top_lds(n_top_copy), stack0(lane_stack) {}
+    DEV bool in_top_copy(uint32_t ref) const { return (ref & kRefTopBit) != 0u && (ref & kRefIndexMask) < n_top_lds; }
     DEV uint32_t end() const { return kRefEnd; }
     DEV bool uniform_times() const { return MOVING && (S.flags & kSceneUniformTimes); }
     DEV void prepare(RayCtx &) const {}
     DEV uint32_t prim_of(uint32_t handle) const { return handle; }
     // (near, far) planes of a box given as (min, max) pairs, for this ray (acceleration.rs:66-71)
-    DEV static void box_test(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t w4, uint32_t w5, const RayCtx &r, float &t0, float &t1) {
+    // t0: entry distance (not below t_min); f: exit distance, scaled (acceleration.rs:77-81).  The box is hit iff t0 <= min(f, t_max).
+    DEV static void box_test(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t w4, uint32_t w5, const RayCtx &r, float &t0, float &f) {
         const bool ngx = r.oct & 1u, ngy = r.oct & 2u, ngz = r.oct & 4u;
         const f32x2 bx = ngx ? f32x2{u2f(w1), u2f(w0)} : f32x2{u2f(w0), u2f(w1)};
         const f32x2 by = ngy ? f32x2{u2f(w3), u2f(w2)} : f32x2{u2f(w2), u2f(w3)};
         const f32x2 bz = ngz ? f32x2{u2f(w5), u2f(w4)} : f32x2{u2f(w4), u2f(w5)};
-        slab_interval(bx, by, bz, r, t0, t1);
+        slab_entry_exit(bx, by, bz, r, t0, f);
     }
     // a leaf's six words: centre at time0, radius^2, sphere word, moving flag
     DEV void leaf_test(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t w4, uint32_t w5, RayCtx &r, bool quick) const {
@@ -523,61 +542,57 @@ struct WideStore {
     // Bvh::hit's first pop (acceleration.rs:236): the root, whose box no record holds
     DEV uint32_t start(RayCtx &r, WideStack &k, uint32_t &n_inner) const {
         k.clear();
+        k.l = stack0;
         if (S.root_ref & kRefLeafBit) return S.root_ref;
-        float t0, t1;
-        box_test(f2u(S.root_box[0]), f2u(S.root_box[1]), f2u(S.root_box[2]), f2u(S.root_box[3]), f2u(S.root_box[4]), f2u(S.root_box[5]), r, t0, t1);
+        float t0, f;
+        box_test(f2u(S.root_box[0]), f2u(S.root_box[1]), f2u(S.root_box[2]), f2u(S.root_box[3]), f2u(S.root_box[4]), f2u(S.root_box[5]), r, t0, f);
         if (COUNT) n_inner++;
-        return t0 <= t1 ? S.root_ref : kRefEnd;
+        return t0 <= fminf(f, r.tmax) ? S.root_ref : kRefEnd;
     }
 };
 
-// `cur` is an inner node whose box the ray is known to hit: deal with its two children.
+// `cur` is an inner node whose box the ray is known to hit: deal with its two children.  A leaf child's sphere is in the
+// record and is tested here, unless the child has to wait for its sibling's subtree.  (Sending every leaf child to the
+// wave's next sphere pass instead, as the walks along exit links do, was slower: 824 ms against 760 on the 1 M-sphere
+// scene.  It saves instructions, but each such leaf then costs a dependent fetch of its own.)
 template <bool MOVING, bool COUNT>
 DEV uint32_t visit_inner(const WideStore<MOVING, COUNT> &st, uint32_t cur, RayCtx &r, WideStack &k, bool quick, uint32_t &n_inner, uint32_t &n_leaf) {
     const uint32_t idx = cur & kRefIndexMask;
     uint4 q0, q1, q2, q3;
-    if (cur & kRefTopBit) { q0 = load4(st.top, idx * 4u); q1 = load4(st.top, idx * 4u + 1u); q2 = load4(st.top, idx * 4u + 2u); q3 = load4(st.top, idx * 4u + 3u); }
-    else { q0 = st.S.wide[idx * 4u]; q1 = st.S.wide[idx * 4u + 1u]; q2 = st.S.wide[idx * 4u + 2u]; q3 = st.S.wide[idx * 4u + 3u]; }
+    if (st.in_top_copy(cur)) { q0 = load4(st.top, idx * 4u); q1 = load4(st.top, idx * 4u + 1u); q2 = load4(st.top, idx * 4u + 2u); q3 = load4(st.top, idx * 4u + 3u); }
+    else { const uint4 *src = ((cur & kRefTopBit) ? st.S.wide_top : st.S.wide) + (size_t)idx * 4u; q0 = src[0]; q1 = src[1]; q2 = src[2]; q3 = src[3]; }
     const uint32_t left = q3.x, right = q3.y & kRefMask;
     const uint32_t axis = (q3.y >> RRT_NODE_AXIS_SHIFT) & 3u;
     const bool right_first = ((r.oct >> axis) & 1u) != 0u;  // acceleration.rs:253-267
+    // entry distance and scaled exit distance of both boxes (of a leaf child: of whatever its words are, never looked at)
+    float lt0, lf, rt0, rf;
+    st.box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, lt0, lf);
+    st.box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r, rt0, rf);
     const uint32_t near_ref = right_first ? right : left, far_ref = right_first ? left : right;
-    // the six words of the near and of the far child
-    const uint32_t n0 = right_first ? q1.z : q0.x, n1 = right_first ? q1.w : q0.y, n2 = right_first ? q2.x : q0.z;
-    const uint32_t n3 = right_first ? q2.y : q0.w, n4 = right_first ? q2.z : q1.x, n5 = right_first ? q2.w : q1.y;
-    const uint32_t f0 = right_first ? q0.x : q1.z, f1 = right_first ? q0.y : q1.w, f2 = right_first ? q0.z : q2.x;
-    const uint32_t f3 = right_first ? q0.w : q2.y, f4 = right_first ? q1.x : q2.z, f5 = right_first ? q1.y : q2.w;
-    bool enter_near = false;
-    if (near_ref & kRefLeafBit) {
+    const float near_t0 = right_first ? rt0 : lt0, near_f = right_first ? rf : lf;
+    const float far_t0 = right_first ? lt0 : rt0, far_f = right_first ? lf : rf;
+    const bool near_leaf = (near_ref & kRefLeafBit) != 0u, far_leaf = (far_ref & kRefLeafBit) != 0u;
+    if (near_leaf) {
         if (COUNT) n_leaf++;
-        st.leaf_test(n0, n1, n2, n3, n4, n5, r, quick);
+        if (right_first) st.leaf_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r, quick);
+        else st.leaf_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, quick);
     } else {
-        float t0, t1;
-        st.box_test(n0, n1, n2, n3, n4, n5, r, t0, t1);
         if (COUNT) n_inner++;
-        enter_near = t0 <= t1;
-    }
-    if (enter_near) {  // the far child waits for the near child's subtree
-        if (far_ref & kRefLeafBit) {
-            k.push(make_uint2(far_ref, 0u));
-        } else {
-            float t0, t1;
-            st.box_test(f0, f1, f2, f3, f4, f5, r, t0, t1);
-            if (t0 <= t1) k.push(make_uint2(far_ref, f2u(t0)));
-            else if (COUNT) n_inner++;  // the reference pops it later and it misses then too
+        if (near_t0 <= fminf(near_f, r.tmax)) {  // Aabb::intersect's last step (acceleration.rs:82-83); the far child waits
+            if (far_leaf || far_t0 <= fminf(far_f, r.tmax)) k.push(make_uint2(far_ref, f2u(far_t0)));
+            else if (COUNT) n_inner++;  // the reference pops it later, and it misses then too: t_max only shrinks
+            return near_ref;
         }
-        return near_ref;
     }
     // the near child is done with (a miss, or a sphere): the far child is the next pop
-    if (far_ref & kRefLeafBit) {
+    if (far_leaf) {
         if (COUNT) n_leaf++;
-        st.leaf_test(f0, f1, f2, f3, f4, f5, r, quick);
+        if (right_first) st.leaf_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, quick);
+        else st.leaf_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r, quick);
         return st.pop(r, k, n_inner);
     }
-    float t0, t1;
-    st.box_test(f0, f1, f2, f3, f4, f5, r, t0, t1);
     if (COUNT) n_inner++;
-    if (t0 <= t1) return far_ref;
+    if (far_t0 <= fminf(far_f, r.tmax)) return far_ref;
     return st.pop(r, k, n_inner);
 }
 
@@ -632,7 +647,7 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     RayCtx r;
     typename Store::Stack stk;
-    uint2 stack_spill[Store::kSpillEntries];
+    uint2 stack_spill[Store::kSpillEntries];  // (two-children walk) stack positions beyond those that LDS holds
     bind_spill(stk, stack_spill);
     ray_load(r, make_float4(0, 0, 0, 0), make_float4(1, 1, 1, 0), make_float4(1, 1, 1, 3), 0.001f, __FLT_MAX__, S, false);
     uint32_t cur = kEnd;
@@ -739,7 +754,6 @@ __global__ __launch_bounds__(kBlockThreads) void k_extend(SceneDev S, PathState 
                                                  wave0 * kWaveSlots, total);
 }
 
-constexpr uint32_t kLdsBlockThreads = 1024;  // 16 waves share one LDS copy of the scene
 
 template <bool MOVING, bool COUNT>
 DEV void extend_lds_block(const SceneDev &S, const PathState &P, uint32_t retire_min, uint32_t leaf_min, uint64_t *wave_stats) {
@@ -818,7 +832,9 @@ __global__ __launch_bounds__(kLdsBlockThreads, 8) void k_extend_top(SceneDev S, 
                                                  wave0 * kWaveSlots, total);
 }
 
-// The same with the two-children records (WideStore): the records of the top levels are walked in an LDS copy.
+// The same with the two-children records (WideStore).  LDS: the first kWideLdsEntries stack positions of every lane
+// (48 KB), then the records of the top seven levels of the tree (8 KB; a larger copy measured no faster).
+constexpr uint32_t kWideTopLds = 127;
 template <bool MOVING, bool COUNT>
 __global__ __launch_bounds__(kLdsBlockThreads, 8) void k_extend_wide(SceneDev S, PathState P, uint32_t retire_min, uint32_t leaf_min,
                                                                    uint64_t *wave_stats) {
@@ -829,7 +845,9 @@ __global__ __launch_bounds__(kLdsBlockThreads, 8) void k_extend_wide(SceneDev S,
     const uint32_t wave = wave0 + (threadIdx.x >> 6);
     const uint32_t own_count = wave < P.wave_end ? rfl(P.qcount[wave]) : 0u;
     if (threadIdx.x < 2) pool[threadIdx.x] = 0u;
-    for (uint32_t i = threadIdx.x; i < S.n_top * 4u; i += kLdsBlockThreads) lds4[i] = S.wide_top[i];
+    const uint32_t n_top_lds = min(S.n_top, kWideTopLds);
+    uint4 *top_copy = lds4 + kWideLdsEntries * kLdsBlockThreads / 2u;  // behind the stacks (8 bytes per entry)
+    for (uint32_t i = threadIdx.x; i < n_top_lds * 4u; i += kLdsBlockThreads) top_copy[i] = S.wide_top[i];
     __syncthreads();
     if (lane == 0 && own_count) atomicAdd(&pool[1], own_count);
     __syncthreads();
@@ -837,7 +855,7 @@ __global__ __launch_bounds__(kLdsBlockThreads, 8) void k_extend_wide(SceneDev S,
     const uint32_t n_lists = min(kLdsBlockThreads / 64u, P.wave_end - wave0);
     const uint32_t total = rfl(pool[1]);
     const bool pooled = total == n_lists * kWaveSlots;
-    const WideStore<MOVING, COUNT> st(S, (LdsNodePtr)lds4);
+    const WideStore<MOVING, COUNT> st(S, (LdsNodePtr)top_copy, n_top_lds, (LdsStackPtr)lds4 + threadIdx.x);
     extend_wave<WideStore<MOVING, COUNT>, MOVING, COUNT>(st, S, P, wave, lane, retire_min, leaf_min, wave_stats, own_count, pooled ? &pool[0] : nullptr,
                                                         wave0 * kWaveSlots, total);
 }
@@ -1589,7 +1607,7 @@ void launch_extend(hipStream_t s, const SceneDev &S, const PathState &P, bool mo
     if (S.top_nodes && S.n_top && S.wide) {
         const uint32_t waves_per_block = kLdsBlockThreads / 64u;
         const dim3 g((P.wave_end - P.wave_begin + waves_per_block - 1u) / waves_per_block), b(kLdsBlockThreads);
-        const size_t lds = (size_t)S.n_top * kNodeWords * 4u;
+        const size_t lds = (size_t)kWideLdsEntries * kLdsBlockThreads * 8u + (size_t)std::min(S.n_top, kWideTopLds) * kNodeWords * 4u;
         if (moving) {
             if (count) hipLaunchKernelGGL((k_extend_wide<true, true>), g, b, lds, s, S, P, retire_min, leaf_min, wave_stats);
             else hipLaunchKernelGGL((k_extend_wide<true, false>), g, b, lds, s, S, P, retire_min, leaf_min, wave_stats);
