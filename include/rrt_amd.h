@@ -114,7 +114,7 @@ typedef struct rrt_render_params {
     uint32_t batch_samples; /* samples per accumulation batch; 0 = library default */
     /* Measurement and tuning knobs, all 0 by default: [0] = n: time every n-th extend launch with HIP events (n in 1, 2,
      * 4, 8; fills rrt_stats.extend_ms / extend_launches); [1] bit 0: walk the HBM copy of the BVH even if the scene fits
-     * LDS; [2], [3]: lanes that must be idle / wait at a sphere before the extend kernel hands out rays / runs a sphere
+     * LDS, bit 1: walk big scenes node by node along the exit links instead of two children per record; [2], [3]: lanes that must be idle / wait at a sphere before the extend kernel hands out rays / runs a sphere
      * pass (0 = library default).  None of them changes a bit of the result. */
     uint32_t reserved[4];
 } rrt_render_params;
