@@ -574,8 +574,9 @@ DEV uint32_t visit_inner(const WideStore<MOVING, COUNT> &st, uint32_t cur, RayCt
     const bool near_leaf = (near_ref & kRefLeafBit) != 0u, far_leaf = (far_ref & kRefLeafBit) != 0u;
     if (near_leaf) {
         if (COUNT) n_leaf++;
-        if (right_first) st.leaf_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r, quick);
-        else st.leaf_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, quick);
+        // (one copy of the sphere test for either side: the words are picked, not the code)
+        st.leaf_test(right_first ? q1.z : q0.x, right_first ? q1.w : q0.y, right_first ? q2.x : q0.z, right_first ? q2.y : q0.w,
+                     right_first ? q2.z : q1.x, right_first ? q2.w : q1.y, r, quick);
     } else {
         if (COUNT) n_inner++;
         if (near_t0 <= fminf(near_f, r.tmax)) {  // Aabb::intersect's last step (acceleration.rs:82-83); the far child waits
@@ -587,8 +588,8 @@ DEV uint32_t visit_inner(const WideStore<MOVING, COUNT> &st, uint32_t cur, RayCt
     // the near child is done with (a miss, or a sphere): the far child is the next pop
     if (far_leaf) {
         if (COUNT) n_leaf++;
-        if (right_first) st.leaf_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, quick);
-        else st.leaf_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r, quick);
+        st.leaf_test(right_first ? q0.x : q1.z, right_first ? q0.y : q1.w, right_first ? q0.z : q2.x, right_first ? q0.w : q2.y,
+                     right_first ? q1.x : q2.z, right_first ? q1.y : q2.w, r, quick);
         return st.pop(r, k, n_inner);
     }
     if (COUNT) n_inner++;
