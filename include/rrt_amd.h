@@ -213,7 +213,9 @@ RRT_API int rrt_validate_scene(const rrt_sphere_soa *spheres, const rrt_material
 /* Host-only: the traversal layout rrt_upload_scene would copy to the GPU.  words16: n_nodes x 16 uint32
  * (inner: box as (min, max) pairs for x, y, z, right ref | axis << 29, left ref, 8 exit links; leaf: centre xyz, radius^2,
  * sphere index, moving flag, 0, 0, 8 exit links).  A ref is a node index, bit 31 set for a leaf,
- * 0x7FFFFFFF for "traversal finished".  For inspection and for tests of the link construction. */
+ * 0x7FFFFFFF for "traversal finished".  scene_flags: bit 0 moving spheres, bit 1 one shutter interval for all of them,
+ * bit 2 centres and radii within the range of the short division, bit 3 radii in [2^-30, 2^30], bit 4 the scene gets the
+ * records of the two-children walk (nodes stay in HBM, tree no deeper than 64).  For inspection and for tests. */
 RRT_API int rrt_debug_layout(const rrt_sphere_soa *spheres, const rrt_material_soa *materials, const rrt_bvh_node *nodes,
                              uint32_t n_nodes, uint32_t *words16, uint32_t *root_ref, uint32_t *scene_flags);
 

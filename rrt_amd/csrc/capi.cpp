@@ -639,7 +639,11 @@ int rrt_debug_layout(const rrt_sphere_soa *sp, const rrt_material_soa *mt, const
         if (rc != RRT_OK) return fail(rc, err);
         if (words16) std::memcpy(words16, L.nodes.data(), L.nodes.size() * 4);
         if (root_ref) *root_ref = L.root_ref;
-        if (scene_flags) *scene_flags = L.flags;
+        if (scene_flags) {  // with the bits the later layout passes add (they rewrite references: after the copies above)
+            make_top_tree(L);
+            make_wide_nodes(L);
+            *scene_flags = L.flags;
+        }
         return RRT_OK;
     } catch (const std::exception &e) { return fail(RRT_ERR_OUT_OF_MEMORY, std::string("rrt_debug_layout: ") + e.what()); }
 }

@@ -306,6 +306,7 @@ void make_wide_nodes(SceneLayout &L) {
     }
     const uint32_t *rw = node_words(L.root_ref);
     for (int k = 0; k < 6; k++) { uint32_t u = rw[k]; std::memcpy(&L.root_box[k], &u, 4); }
+    L.flags |= kSceneWideRecords;
 }
 
 }  // namespace rrt_amd

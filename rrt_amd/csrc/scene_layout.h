@@ -49,6 +49,10 @@ constexpr uint32_t kSceneBounded = 4u;
 // every radius has a magnitude in [2^-30, 2^30]: the shade kernel may divide by it through its reciprocal
 constexpr uint32_t kSceneRadiiNormal = 8u;
 
+// (set by make_wide_nodes) the layout has the records of the two-children walk: the nodes stay in HBM and the tree is no
+// deeper than that walk's stack
+constexpr uint32_t kSceneWideRecords = 16u;
+
 struct Float4 { float x, y, z, w; };
 
 struct SceneLayout {

@@ -548,6 +548,26 @@ def test_large_scene_with_moving_spheres(gpu_ctx, uniform_times):
         assert_same_image(gpu_ctx.render(rrt_amd.Context.params(nx, ny, ns, seed=9, exit_link_walk=exit_links)), ref)
 
 
+def test_deep_tree_falls_back_to_the_exit_link_walk(gpu_ctx):
+    """A tree about 100 levels deep (more than the two-children walk's stack holds) in a scene too big for LDS."""
+    from tests.test_host_mirror import deep_tree_scene
+    sp, mid, mt, cam = deep_tree_scene()
+    osc = OracleScene.from_arrays(sp, mid, mt, np.zeros((0, 8), np.uint32), cam.as_array())
+    osc.build_bvh(0)
+    _, _, _, nd, _ = scene_arrays_from_oracle(osc)
+    assert rrt_amd.debug_layout(sp, mid, mt, nd)[2] & 16 == 0
+    gpu_ctx.upload_scene(sp, mid, mt, nd)
+    gpu_ctx.set_camera(cam)
+    # camera rays only (depth limit 0: every hit is black): a scattered ray could run down the whole row of spheres, and
+    # then the reference's 64-entry stack (acceleration.rs:233) overflows and the reference panics (as does the oracle)
+    nx, ny, ns = 64, 48, 4
+    ref = osc.render(nx, ny, ns, seed=2, threads=8, max_depth=0)
+    gpu = gpu_ctx.render(rrt_amd.Context.params(nx, ny, ns, seed=2, max_depth=0, count_work=True))
+    assert_same_image(gpu, ref)
+    assert gpu[2]["inner_visits"] == ref[2]["inner_visits"] and gpu[2]["leaf_tests"] == ref[2]["leaf_tests"]
+    assert ref[2]["depth_cut"] > 200 and ref[2]["sky_misses"] > 200
+
+
 def test_million_sphere_scene_spot(gpu_ctx):
     """The big-scene configuration: 1000x1000 cells (~1 M spheres, ~2 M nodes), 1920x1080 at 256 spp; spot-checked pixels."""
     nx, ny, ns, half = 1920, 1080, 256, 500

@@ -161,7 +161,9 @@ def test_layout_flags_moving_scene():
     sp2 = sp.copy()
     k = np.nonzero((sp[:, 0:3] != sp[:, 3:6]).any(axis=1))[0][0]
     sp2[k, 7] = 2.0
-    assert rrt_amd.debug_layout(sp2, mid, mt, nd)[2] == 9  # another shutter interval: not uniform, and then not "bounded" either
+    # another shutter interval: not uniform, and then not "bounded" either; such a scene is not walked in LDS and gets the
+    # records of the two-children walk (bit 4)
+    assert rrt_amd.debug_layout(sp2, mid, mt, nd)[2] == 25
     # a centre or a radius out of the short division's range takes bit 2 away and nothing else
     for col, val in [(0, 3.0e9), (5, -1.0e9), (8, 2.0e9), (1, np.nan)]:
         sp3 = sp.copy()
@@ -174,6 +176,44 @@ def test_layout_flags_moving_scene():
         sp3 = sp.copy()
         sp3[k, 8] = val
         assert rrt_amd.debug_layout(sp3, mid, mt, nd)[2] & 8 == 0
+
+
+def deep_tree_scene(n=1500):
+    """Spheres along the x axis at geometrically growing distances (2^-40 .. 2^40): every middle split peels a few of the
+    farthest off, so the reference's tree is about 80 levels deep.  A ray that walked down all of them would overflow
+    the reference's 64-entry stack (acceleration.rs:233); the camera that comes with the scene looks across the far end
+    of the row, where the walk stays shallow."""
+    sp = np.zeros((n, 9), np.float32)
+    x = 2.0 ** (-40.0 + 80.0 * np.arange(n, dtype=np.float64) / n)
+    sp[:, 0] = sp[:, 3] = x.astype(np.float32)
+    sp[:, 1] = sp[:, 4] = (0.01 * x).astype(np.float32) * np.where(np.arange(n) % 2, 1.0, -1.0).astype(np.float32)
+    sp[:, 7] = 1.0
+    sp[:, 8] = (0.012 * x).astype(np.float32)
+    mt = np.zeros((n, 6), np.float32)
+    mt[:, 0] = np.arange(n) % 3
+    mt[:, 1:4] = 0.7
+    mt[:, 4] = 0.1
+    mt[:, 5] = 1.5
+    far = float(2.0 ** 40)
+    cam = rrt_amd.camera_from((0.7 * far, 0.0, 0.5 * far), (0.7 * far, 0.0, 0.0), (0, 1, 0), 40.0, 4.0 / 3.0, 0.0, 0.5 * far, 0.0, 0.0)
+    return sp, np.arange(n, dtype=np.uint32), mt, cam
+
+
+def test_layout_flag_of_the_two_children_walk():
+    """Bit 4: scenes whose nodes stay in HBM get two-children records unless the tree is deeper than the walk's stack."""
+    from oracle import OracleScene
+    small = OracleScene.build(1, 32, 32, seed=0)
+    sp, mid, mt, nd, _ = scene_arrays_from_oracle(small)
+    assert rrt_amd.debug_layout(sp, mid, mt, nd)[2] & 16 == 0      # walked in LDS
+    big = OracleScene.build(3, 32, 32, seed=0, half=60)
+    sp, mid, mt, nd, _ = scene_arrays_from_oracle(big)
+    assert rrt_amd.debug_layout(sp, mid, mt, nd)[2] & 16 == 16
+    sp, mid, mt, cam = deep_tree_scene()
+    deep = OracleScene.from_arrays(sp, mid, mt, np.zeros((0, 8), np.uint32), cam.as_array())
+    deep.build_bvh(0)
+    _, _, _, nd, _ = scene_arrays_from_oracle(deep)
+    assert nd.shape[0] == 2 * sp.shape[0] - 1
+    assert rrt_amd.debug_layout(sp, mid, mt, nd)[2] & 16 == 0      # deeper than 64 levels: the exit-link walk
 
 
 def test_scene_validation_errors():
