@@ -67,6 +67,21 @@ def test_noalloc_matches_render_device_twice_in_a_row(gpu_ctx):
     assert torch.cuda.mem_get_info()[0] >= free_before - (4 << 20)
 
 
+def test_noalloc_on_a_scene_too_big_for_lds(gpu_ctx):
+    """14 k spheres: rrt_render_device walks two children per record (a kernel with a stack in scratch memory, which the
+    runtime allocates), the entry point that allocates nothing walks the same tree along exit links.  Same image."""
+    nx, ny, ns, half = 72, 40, 3, 60
+    hs = rrt_amd.HostScene(rrt_amd.SCENE_RANDOM_SPHERES, nx, ny, seed=0, half=half)
+    gpu_ctx.upload_host_scene(hs)
+    (rgb_a, acc_a, st_a), (rgb_n, acc_n, st_n) = _both(gpu_ctx, rrt_amd.Context.params(nx, ny, ns, seed=4, count_work=True))
+    assert np.array_equal(bits(acc_n), bits(acc_a)) and np.array_equal(rgb_n, rgb_a)
+    for key in ("rays", "paths", "inner_visits", "leaf_tests"):
+        assert st_n[key] == st_a[key], key
+    osc = OracleScene.build(rrt_amd.SCENE_RANDOM_SPHERES, nx, ny, seed=0, half=half)
+    ref = osc.render(nx, ny, ns, seed=4, threads=8)
+    assert np.array_equal(bits(acc_n), bits(ref[1].reshape(-1))) and st_n["inner_visits"] == ref[2]["inner_visits"]
+
+
 def test_noalloc_rejects_what_does_not_fit(gpu_ctx):
     osc = OracleScene.build(rrt_amd.SCENE_CHAP11, 8, 8)
     _upload(gpu_ctx, osc)
