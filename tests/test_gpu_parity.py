@@ -83,6 +83,34 @@ def test_intersect_random_and_degenerate_rays(gpu_ctx, name):
     assert np.array_equal(bits(t_b), bits(t_o))
 
 
+def test_intersect_degenerate_rays_in_a_big_scene(gpu_ctx):
+    """The same kinds of rays through the walk of scenes whose nodes stay in HBM (two children per record, far children on
+    a stack): zero and negative-zero direction components, huge and tiny directions, far-away origins, and origins
+    inside the field of spheres, where many boxes overlap the ray's start."""
+    osc = OracleScene.build(rrt_amd.SCENE_RANDOM_SPHERES, 64, 64, seed=3, half=60)
+    upload_from_oracle(gpu_ctx, osc)
+    rng = np.random.default_rng(6)
+    n = 30000
+    org = rng.uniform(-70, 70, (n, 3)).astype(np.float32)
+    org[:, 1] = rng.uniform(0.05, 3.0, n)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d[:, 1] *= np.float32(0.2)            # mostly along the ground, through many spheres' boxes
+    d[0:3000, 0] = 0.0
+    d[3000:6000, 1] = 0.0
+    d[6000:9000, 2] = -0.0
+    d[9000:9500, 0:2] = 0.0
+    d[9500:11000] *= np.float32(1e6)
+    d[11000:12500] *= np.float32(1e-6)
+    org[12500:13000, 0] += np.float32(3e9)
+    org[13000:13500, 1] = np.float32(0.2)  # at the height of the small spheres' centres
+    tm = rng.uniform(0, 1, n).astype(np.float32)
+    t_o, obj_o, _, _, _ = osc.hit_rays(org, d, tm)
+    t_g, obj_g = gpu_ctx.intersect(org, d, tm)
+    assert np.array_equal(obj_g, obj_o)
+    assert np.array_equal(bits(t_g), bits(t_o))
+    assert (obj_o != 0xFFFFFFFF).sum() > 10000 and (obj_o > 0).sum() > 1000  # not only the ground
+
+
 # ---------------------------------------------------------------- whole path: tracescene
 @pytest.mark.parametrize("name,nx,ny,ns", [
     ("chap11", 40, 23, 8),       # the chap11 fixture shape
