@@ -15,3 +15,7 @@ for _ in range(3):
     t0 = time.perf_counter(); got = ctx.build_bvh(sp); ts.append(time.perf_counter() - t0)
 print(f"{sp.shape[0]} spheres, {nd.shape[0]} nodes: host scene + BVH build {t_host:.2f} s; rrt_build_bvh {min(ts) * 1e3:.1f} ms "
       f"(planes up, nodes back, included); identical: {np.array_equal(got, nd)}")
+ts = []
+for _ in range(3):
+    t0 = time.perf_counter(); ctx.upload_host_scene(hs); ts.append(time.perf_counter() - t0)
+print(f"rrt_upload_scene (validation, node words, exit links, top-of-tree copy, two-children records, copies to the device): {min(ts):.2f} s")
