@@ -950,10 +950,10 @@ struct SlotIn {
     uint2 h;
     uint32_t depth;
     uint4 recent;  // the four most recent trail entries, newest first
-    float4 sph, mat;  // (tables in HBM only) the hit sphere's table rows, fetched with the rest of the state
+    float4 sph;  // (tables in HBM only) the hit sphere's row of the sphere table, fetched with the rest of the state
 };
-// `hit_word` is the sphere word of the slot's hit record as step 1 saw it, or kPrimNone: with it the table rows can be
-// asked for at once, a tile ahead, instead of by a dependent gather in the middle of the tile.
+// `hit_word` is the sphere word of the slot's hit record as step 1 saw it, or kPrimNone: with it the sphere's table row can
+// be asked for at once, a tile ahead, instead of by a dependent gather in the middle of the tile.
 template <bool PREFETCH_ROWS, bool TIMED, bool NARROW>
 DEV void load_slot(const SceneDev &S, const PathState &P, uint32_t slot, uint32_t hit_word, SlotIn &in) {
     // Every lane loads, whether its list position is taken or not (`slot` is always a slot of this wave, a miss reads
@@ -963,7 +963,7 @@ DEV void load_slot(const SceneDev &S, const PathState &P, uint32_t slot, uint32_
     in.A = origin_load(P, slot, TIMED); in.B = P.rayB[slot]; in.h = P.hit[slot]; meta_load(P, slot, NARROW, in.depth, in.recent);
     if (PREFETCH_ROWS) {
         const uint32_t row = hit_word != kPrimNone ? hit_word & kLeafPrimMask : 0u;
-        in.sph = S.sph[row]; in.mat = S.prim_att[row];
+        in.sph = S.sph[row];
     }
 }
 
@@ -1075,7 +1075,9 @@ DEV void shade_slot(const SceneDev &S, const Tables &T, const PathState &P, cons
         const uint32_t prim = in.h.y & kLeafPrimMask;
         const float t = u2f(in.h.x);
         const float4 sp = Tables::kInLds ? T.sphere(prim) : in.sph;
-        const float4 mrow = Tables::kInLds ? T.material(prim) : in.mat;  // metal: .w = fuzz; glass: 1/ior, r0 seen from outside, r0 from inside, ior
+        // (tables in HBM: the material row is gathered here, not a tile ahead with the sphere row: the eight registers that
+        // holding it in both tile buffers takes are the difference between three and four waves per SIMD)
+        const float4 mrow = T.material(prim);  // metal: .w = fuzz; glass: 1/ior, r0 seen from outside, r0 from inside, ior
         const float mat_param = mrow.w;
         V3 c = mk(sp.x, sp.y, sp.z);
         if (MOVING) {
@@ -1242,7 +1244,7 @@ DEV uint32_t shade_wave(const SceneDev &S, const PathState &P, const BatchDev &B
             }
         }
         buf[0].h = h[0]; buf[0].depth = dep[0];
-        if (!TABLES) { const uint32_t row = hw[0] != kPrimNone ? hw[0] & kLeafPrimMask : 0u; buf[0].sph = S.sph[row]; buf[0].mat = S.prim_att[row]; }
+        if (!TABLES) { const uint32_t row = hw[0] != kPrimNone ? hw[0] & kLeafPrimMask : 0u; buf[0].sph = S.sph[row]; }
     }
     const uint32_t n_tiles = (count + 63u) >> 6;
     // one cursor update for every path known to end; the answer is not needed before step 3
@@ -1413,7 +1415,7 @@ DEV uint32_t shade_wave(const SceneDev &S, const PathState &P, const BatchDev &B
 }
 
 template <bool MOVING, bool COUNT, bool TABLES>
-__global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads, TABLES ? 4 : 3) void k_shade(SceneDev S, PathState P, BatchDev Bt, CameraDev C,
+__global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads, (TABLES || !MOVING) ? 4 : 3) void k_shade(SceneDev S, PathState P, BatchDev Bt, CameraDev C,
                                                                                       uint64_t *wave_stats) {
     constexpr uint32_t kThreads = TABLES ? kShadeTableThreads : kBlockThreads;
     extern __shared__ uint4 lds4[];  // per wave kShadeLdsWords words, then (TABLES) the sphere and material tables
