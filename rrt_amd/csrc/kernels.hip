@@ -701,6 +701,9 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
             uint64_t im = __ballot(at_inner);
             if (im == 0ull) break;
             if (COUNT) { d_desc_iters++; d_desc_lanes += (uint32_t)__popcll(im); }
+#ifdef RRT_DRAIN_STATS  // (tools/drain_stats.py) the sphere-pass counters count the descent passes made with nothing left to take instead
+            if (COUNT && head >= count) { d_leaf_iters++; d_leaf_lanes += (uint32_t)__popcll(im); }
+#endif
             if (at_inner) {
                 if (COUNT && !Store::kCountsItself) n_inner++;
                 cur = visit_inner(st, cur, r, stk, quick, n_inner, n_leaf);
@@ -709,13 +712,18 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
             im = __ballot(at_inner);
             if (im == 0ull) break;
             if (COUNT) { d_desc_iters++; d_desc_lanes += (uint32_t)__popcll(im); }
+#ifdef RRT_DRAIN_STATS
+            if (COUNT && head >= count) { d_leaf_iters++; d_leaf_lanes += (uint32_t)__popcll(im); }
+#endif
             if (at_inner) {
                 if (COUNT && !Store::kCountsItself) n_inner++;
                 cur = visit_inner(st, cur, r, stk, quick, n_inner, n_leaf);
             }
             if ((uint32_t)__popcll(__ballot(cur > kEnd)) >= leaf_min) break;
         }
+#ifndef RRT_DRAIN_STATS
         if (COUNT) { const uint64_t lm = __ballot(cur > kEnd); if (lm) { d_leaf_iters++; d_leaf_lanes += (uint32_t)__popcll(lm); } }
+#endif
         if (cur > kEnd) {
             if (COUNT && !Store::kCountsItself) n_leaf++;
             cur = visit_leaf(st, cur, r, stk, quick, n_inner, n_leaf);
