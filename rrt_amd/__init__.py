@@ -24,8 +24,15 @@ NODE_AXIS_SHIFT = 29
 NODE_INDEX_MASK = 0x1FFFFFFF
 
 
+ERR_INVALID_ARGUMENT, ERR_HIP, ERR_NO_DEVICE, ERR_BAD_SCENE, ERR_OUT_OF_MEMORY, ERR_NOT_READY = -1, -2, -3, -4, -5, -6  # rrt_status
+
+
 class RrtError(RuntimeError):
-    pass
+    """A call of the library returned a negative rrt_status (`code`)."""
+
+    def __init__(self, message: str, code: int = 0):
+        super().__init__(message)
+        self.code = code
 
 
 class SphereSoa(C.Structure):
@@ -155,7 +162,7 @@ def lib() -> C.CDLL:
 
 def _check(rc: int, what: str) -> None:
     if rc != 0:
-        raise RrtError(f"{what} failed ({rc}): {lib().rrt_last_error().decode()}")
+        raise RrtError(f"{what} failed ({rc}): {lib().rrt_last_error().decode()}", rc)
 
 
 def _fptr(a: np.ndarray):

@@ -122,6 +122,10 @@ struct rrt_ctx {
     std::vector<hipEvent_t> kev;   // event pairs around extend launches
     // scratch for rrt_intersect
     DevBuf q_org, q_dir, q_time, q_t, q_obj;
+    // the pixel list of the last TILE shard rendered, kept on the device: a rank renders the same shard frame after frame
+    DevBuf tile_map;
+    uint32_t tile_map_key[4] = {0, 0, 0, 0};  // nx, ny, rank, world (nx == 0: none)
+    uint32_t tile_map_len = 0;
 };
 
 extern "C" {
@@ -172,7 +176,7 @@ void rrt_destroy(rrt_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (hipStream_t ss : c->side_stream) if (ss) (void)hipStreamSynchronize(ss);
     for (DevBuf *b : {&c->nodes, &c->small_nodes, &c->top_nodes, &c->wide, &c->wide_top, &c->sph, &c->motion, &c->motion_dt, &c->sph_info, &c->prim_att,
-                      &c->tmp_rgb, &c->tmp_acc, &c->q_org, &c->q_dir, &c->q_time, &c->q_t, &c->q_obj})
+                      &c->tmp_rgb, &c->tmp_acc, &c->q_org, &c->q_dir, &c->q_time, &c->q_t, &c->q_obj, &c->tile_map})
         b->release();
     for (DevBuf &b : c->ws) b.release();
     for (hipEvent_t ev : c->kev) (void)hipEventDestroy(ev);
@@ -305,6 +309,11 @@ struct RenderTarget {
     size_t workspace_bytes = 0;                      // out of this memory and allocate nothing
 };
 
+// The progress word is read by another thread while the render runs (main.rs:78-94 polls `pdc`): relaxed atomic accesses,
+// as the reference's fetch_add(1, Relaxed) / load(Relaxed).
+uint64_t progress_now(volatile uint64_t *p) { return __atomic_load_n(const_cast<uint64_t *>(p), __ATOMIC_RELAXED); }
+void progress_set(volatile uint64_t *p, uint64_t v) { __atomic_store_n(const_cast<uint64_t *>(p), v, __ATOMIC_RELAXED); }
+
 // Waits for everything the context has queued, on every stream.  Error paths call it so that no kernel of a failed
 // render is still running on a side stream when the caller's next call reuses the buffers.
 void drain(rrt_ctx *c) {
@@ -325,7 +334,7 @@ int render_impl(rrt_ctx *c, const rrt_render_params *pp, const RenderTarget &T) 
     const uint32_t rank = P.shard_mode == RRT_SHARD_NONE ? 0u : P.shard_rank;
     if (P.shard_mode > RRT_SHARD_SAMPLE || world == 0 || rank >= world) return fail(RRT_ERR_INVALID_ARGUMENT, "bad shard description");
     HIP_TRY(hipSetDevice(c->device));
-    if (T.progress) *T.progress = 0;
+    if (T.progress) progress_set(T.progress, 0);
     rrt_stats st{};
     size_t kev_used = 0;
     uint32_t n_waves = 0;
@@ -370,12 +379,22 @@ int render_queued(rrt_ctx *c, const rrt_render_params &P, const RenderTarget &T,
     // ---- which pixels and which samples this call renders ----
     RenderPlan pl;
     pl.npix = npix_img;
-    std::vector<uint32_t> map;
+    const uint32_t *d_map = nullptr;
     if (P.shard_mode == RRT_SHARD_TILE && world > 1) {
         if (no_alloc) return fail(RRT_ERR_INVALID_ARGUMENT, "the no-allocation entry point takes RRT_SHARD_NONE or RRT_SHARD_SAMPLE only");
-        tile_pixels(P.nx, P.ny, rank, world, map);
-        pl.npix = (uint32_t)map.size();
-        pl.want_map = true;
+        const uint32_t key[4] = {P.nx, P.ny, rank, world};
+        if (std::memcmp(key, c->tile_map_key, sizeof key) != 0) {  // another shard than last time: list its pixels and upload them
+            std::vector<uint32_t> map;
+            tile_pixels(P.nx, P.ny, rank, world, map);
+            c->tile_map_key[0] = 0;
+            HIP_TRY(c->tile_map.ensure(std::max<size_t>(16, map.size() * 4)));
+            HIP_TRY(hipMemcpyAsync(c->tile_map.p, map.data(), map.size() * 4, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipStreamSynchronize(s));  // pageable source
+            c->tile_map_len = (uint32_t)map.size();
+            std::memcpy(c->tile_map_key, key, sizeof key);
+        }
+        pl.npix = c->tile_map_len;
+        d_map = c->tile_map.as<uint32_t>();
     }
     const uint32_t npix = pl.npix;
     uint32_t k_first = 0, k_step = 1, ns_local = P.ns;
@@ -444,13 +463,6 @@ int render_queued(rrt_ctx *c, const rrt_render_params &P, const RenderTarget &T,
         n_waves_out = n_waves;
         auto at = [&](int i) { return piece[i]; };
 
-        const uint32_t *d_map = nullptr;
-        if (pl.want_map) {
-            HIP_TRY(hipMemcpyAsync(at(WS_PIXEL_MAP), map.data(), map.size() * 4, hipMemcpyHostToDevice, s));
-            HIP_TRY(hipStreamSynchronize(s));  // pageable source
-            d_map = static_cast<const uint32_t *>(at(WS_PIXEL_MAP));
-        }
-
         PathState ps{};
         ps.rayA = static_cast<float4 *>(at(WS_RAYA)); ps.rayB = static_cast<float4 *>(at(WS_RAYB));
         ps.recent = static_cast<uint4 *>(at(WS_RECENT)); ps.rng = static_cast<uint4 *>(at(WS_RNG));
@@ -481,8 +493,7 @@ int render_queued(rrt_ctx *c, const rrt_render_params &P, const RenderTarget &T,
             part[h].wave_end = (uint32_t)((uint64_t)n_waves * (h + 1) / n_parts);
             part_stream[h] = h == 0 ? s : c->side_stream[h - 1];
         }
-        const uint64_t total_paths = (uint64_t)ns_local * npix;
-        uint32_t chunk = kChunk;
+            uint32_t chunk = kChunk;
         // (not for the entry point that must allocate nothing: the finishing kernel spills a few registers, and the runtime
         // allocates the memory spills go to when such a kernel is first launched)
         const bool can_finish = !no_alloc && finish_fits(sd, ps) && !std::getenv("RRT_NO_FINISH");
@@ -555,8 +566,8 @@ int render_queued(rrt_ctx *c, const rrt_render_params &P, const RenderTarget &T,
                     for (uint32_t k = 0; k < kCursorShards; k++) claimed += c->h_flags[kFlagWords + k * kCursorStride];
                     claimed = std::min<uint64_t>(claimed, bd.n_paths);
                     const uint64_t finished = (uint64_t)s0 * npix + (any ? (claimed > slots ? claimed - slots : 0) : bd.n_paths);
-                    const uint64_t px = finished * npix / total_paths;
-                    if (px > *T.progress) *T.progress = px;
+                    const uint64_t px = finished / ns_local;  // of total_paths = ns_local * npix paths: finished * npix / total_paths
+                    if (px > progress_now(T.progress)) progress_set(T.progress, px);
                 }
                 if (!any) break;
             }
@@ -570,7 +581,7 @@ int render_queued(rrt_ctx *c, const rrt_render_params &P, const RenderTarget &T,
     HIP_TRY(hipEventRecord(c->ev1, s));
     HIP_TRY(hipStreamSynchronize(s));
     HIP_TRY(hipGetLastError());
-    if (T.progress) *T.progress = npix;  // every pixel of this call is finished (lib.rs:109)
+    if (T.progress) progress_set(T.progress, npix);  // every pixel of this call is finished (lib.rs:109)
     return RRT_OK;
 }
 

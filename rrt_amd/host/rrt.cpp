@@ -406,7 +406,7 @@ std::vector<uint8_t> tracescene(size_t nx, size_t ny, size_t ns, const Scene &sc
     std::mutex mu;
     std::condition_variable wake;
     auto forward = [&] {
-        const uint64_t now = done;
+        const uint64_t now = __atomic_load_n(const_cast<const uint64_t *>(&done), __ATOMIC_RELAXED);  // written by the render's thread(s)
         if (now > forwarded) { pdc.fetch_add(static_cast<size_t>(now - forwarded), std::memory_order_relaxed); forwarded = now; }
     };
     std::thread relay([&] {  // looks every 20 ms, and leaves at once when the render returns

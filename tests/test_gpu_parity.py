@@ -408,6 +408,26 @@ def test_errors(gpu_ctx):
 
 
 # ---------------------------------------------------------------- full-size configurations
+def assert_matches_fullsize_digest(name, rgb, acc, st):
+    """Every pixel of a whole render against the digests of the oracle's render of the same configuration
+    (tests/golden/fullsize.json, written by tests/golden/make_fullsize.py): CRC-32 of every row of f32 sums, SHA-256 of the
+    sums and of the RGB8 bytes, and all ten work counters that the render reports without the counting build."""
+    import hashlib
+    import json
+    import zlib
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize.json")) as f:
+        g = json.load(f)[name]
+    nx, ny = g["nx"], g["ny"]
+    acc = np.ascontiguousarray(acc.reshape(ny, nx, 3), np.float32)
+    rows = [zlib.crc32(acc[y].tobytes()) for y in range(ny)]
+    bad = [y for y in range(ny) if rows[y] != g["row_crc32"][y]]
+    assert not bad, f"{len(bad)} of {ny} rows of f32 sums differ, first: {bad[:8]}"
+    assert hashlib.sha256(acc.tobytes()).hexdigest() == g["sha256_acc"]
+    assert hashlib.sha256(np.ascontiguousarray(rgb.reshape(ny, nx, 3), np.uint8).tobytes()).hexdigest() == g["sha256_rgb"]
+    assert st["rays"] == g["counters"]["rays"] and st["paths"] == nx * ny * g["ns"]
+    return g
+
+
 def spot_check(gpu_ctx, kind, nx, ny, ns, seed, n_pixels, scene_seed=0, half=11):
     osc = OracleScene.build(kind, nx, ny, seed=scene_seed, half=half)
     upload_from_oracle(gpu_ctx, osc)
@@ -463,6 +483,13 @@ def test_cfg4_4k_1024spp_unsharded_spot(gpu_ctx, cfg4_unsharded):
     assert np.array_equal(rgb.reshape(-1, 3)[idx], rgb_o)
     assert st["paths"] == nx * ny * ns
     assert rgb.mean() > 20
+
+
+def test_cfg4_4k_1024spp_whole_image_digest(gpu_ctx, cfg4_unsharded):
+    """All 8.3 M pixels of the target configuration against the oracle's render (2.4e10 rays, rendered once on the CPU)."""
+    osc, rgb, acc, st, idx = cfg4_unsharded
+    g = assert_matches_fullsize_digest("chap12_3840x2160x1024", rgb, acc, st)
+    assert (g["nx"], g["ny"], g["ns"]) == CFG4
 
 
 def test_cfg4_4k_1024spp_as_8_tile_shards(gpu_ctx, cfg4_unsharded):
@@ -610,6 +637,9 @@ def test_million_sphere_scene_spot(gpu_ctx):
     assert np.array_equal(bits(acc.reshape(-1, 3)[idx]), bits(acc_o))
     assert np.array_equal(rgb.reshape(-1, 3)[idx], rgb_o)
     assert st["paths"] == nx * ny * ns
+    # and every pixel against the digests of the oracle's render of the whole image (4.4e9 rays)
+    g = assert_matches_fullsize_digest("spheres1m_1920x1080x256", rgb, acc, st)
+    assert (g["nx"], g["ny"], g["ns"], g["half"]) == (nx, ny, ns, half)
 
 
 def test_cli_renders_the_reference_default_scene(gpu_ctx, tmp_path):
@@ -633,22 +663,14 @@ def test_cli_renders_the_reference_default_scene(gpu_ctx, tmp_path):
 def test_full_size_image_digests(gpu_ctx, name):
     """Whole images at the headline sizes against digests of the oracle's renders (tests/golden/make_fullsize.py):
     every pixel of every row, f32 sums and RGB8, and the ray count."""
-    import hashlib
     import json
-    import zlib
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize.json")) as f:
         g = json.load(f)[name]
     nx, ny, ns = g["nx"], g["ny"], g["ns"]
     hs = rrt_amd.HostScene(g["kind"], nx, ny, seed=g["scene_seed"])
     gpu_ctx.upload_host_scene(hs)
     rgb, acc, st = gpu_ctx.render(rrt_amd.Context.params(nx, ny, ns, seed=g["seed"], max_depth=g["max_depth"]))
-    acc = np.ascontiguousarray(acc.reshape(ny, nx, 3), np.float32)
-    rows = [zlib.crc32(acc[y].tobytes()) for y in range(ny)]
-    bad = [y for y in range(ny) if rows[y] != g["row_crc32"][y]]
-    assert not bad, f"{len(bad)} of {ny} rows of f32 sums differ, first: {bad[:8]}"
-    assert hashlib.sha256(acc.tobytes()).hexdigest() == g["sha256_acc"]
-    assert hashlib.sha256(np.ascontiguousarray(rgb.reshape(ny, nx, 3), np.uint8).tobytes()).hexdigest() == g["sha256_rgb"]
-    assert st["rays"] == g["counters"]["rays"] and st["paths"] == nx * ny * ns
+    assert_matches_fullsize_digest(name, rgb, acc, st)
 
 
 @pytest.mark.parametrize("kind,half", [(rrt_amd.SCENE_CHAP11, 0), (rrt_amd.SCENE_CHAP12, 0), (rrt_amd.SCENE_BOOK2CHAP2, 0),
@@ -767,6 +789,50 @@ def test_render_multi_one_call_whole_image(gpu_ctx, monkeypatch):
             c.close()
 
 
+def test_render_multi_returns_when_one_rank_fails(gpu_ctx, monkeypatch):
+    """A rank that cannot render (here: its context has no scene) must make the call return its error; the other ranks must not
+    be left waiting for its side of the exchange.  Every rank is joined before any of them enters the exchange."""
+    nx, ny, ns = 96, 64, 4
+    osc = OracleScene.build(SCENES["chap12"], nx, ny, seed=0)
+    upload_from_oracle(gpu_ctx, osc)
+    bare = rrt_amd.Context(0)   # no scene, no camera
+    try:
+        monkeypatch.setenv("RRT_MULTI_LOOPBACK", "1")
+        for mode in (rrt_amd.SHARD_TILE, rrt_amd.SHARD_SAMPLE):
+            for order in ([gpu_ctx, bare], [bare, gpu_ctx]):
+                with pytest.raises(rrt_amd.RrtError, match="rank failed") as e:
+                    rrt_amd.render_multi(order, rrt_amd.Context.params(nx, ny, ns, seed=3, shard_mode=mode))
+                assert e.value.code == rrt_amd.ERR_NOT_READY
+        # the good context still renders afterwards, alone and with a good peer
+        upload_from_oracle(bare, osc)
+        ref = osc.render(nx, ny, ns, seed=3, threads=8)
+        assert_same_image(rrt_amd.render_multi([gpu_ctx, bare], rrt_amd.Context.params(nx, ny, ns, seed=3, shard_mode=rrt_amd.SHARD_TILE)), ref)
+    finally:
+        bare.close()
+
+
+def test_more_sample_shards_than_samples(gpu_ctx, monkeypatch):
+    """world > ns under SAMPLE sharding: the ranks past the last sample render nothing (zero sums, zero counters, a zero
+    image of their own) and the combined image is the whole render's."""
+    nx, ny, ns = 64, 40, 2
+    osc = OracleScene.build(SCENES["chap11"], nx, ny)
+    ref = osc.render(nx, ny, ns, seed=5, threads=8)
+    ctxs = [gpu_ctx, rrt_amd.Context(0), rrt_amd.Context(0)]
+    try:
+        for c in ctxs:
+            upload_from_oracle(c, osc)
+        rgb, acc, st = gpu_ctx.render(rrt_amd.Context.params(nx, ny, ns, seed=5, shard_mode=rrt_amd.SHARD_SAMPLE, rank=2, world=3))
+        assert not rgb.any() and not acc.any() and st["rays"] == 0 and st["paths"] == 0
+        monkeypatch.setenv("RRT_MULTI_LOOPBACK", "1")
+        rgb, acc, st = rrt_amd.render_multi(ctxs, rrt_amd.Context.params(nx, ny, ns, seed=5, shard_mode=rrt_amd.SHARD_SAMPLE))
+        assert st["rays"] == ref[2]["rays"] and st["paths"] == nx * ny * ns
+        # two ranks with one sample each and one with none: 0 + a + b in rank order is the one-GPU sum a + b bit for bit
+        assert np.array_equal(bits(acc), bits(ref[1])) and np.array_equal(rgb, ref[0])
+    finally:
+        for c in ctxs[1:]:
+            c.close()
+
+
 def test_render_multi_on_two_gpus_over_rccl(gpu_ctx):
     """The same call on two real GPUs, shares moved by RCCL.  Skipped where the machine has one GPU."""
     try:
@@ -798,9 +864,13 @@ def test_two_process_render_over_nccl(gpu_ctx):
     except rrt_amd.RrtError:
         pytest.skip("one GPU here")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import socket
     for shard in ("tile", "sample"):
+        with socket.socket() as sock:   # a port nobody listens on right now
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
         r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                            "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--spp", "16",
+                            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--spp", "16",
                             "--shard", shard, "--no-roofline"], capture_output=True, text=True, timeout=600, cwd=root)
         assert r.returncode == 0, r.stderr[-2000:]
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
