@@ -56,9 +56,17 @@ def job_flops(st):
             + 54 * st["hits_metal"] + 45 * st["hits_dielectric"] + 22 * st["sky_misses"] + 45 * st["paths"])
 
 
-def extend_bytes(st):
-    """Algorithmic bytes the extend kernel moves to and from HBM: per ray 48 B of ray state + 4 B list entry in, 8 B hit
-    out.  (The BVH — 32 B per box test, 16 B per sphere test — is read from the LDS copy, not from HBM.)"""
+def extend_bytes(st, moving=False):
+    """Bytes the extend kernel moves to and from HBM as it is built: per ray the origin (12 B; 16 B with the shutter time in
+    scenes with moving spheres) and the direction with the path id (16 B) in, the 8-byte hit record out.  The live-slot list
+    of a wave whose 256 slots are all alive is the identity and is not read; 1/direction and direction.direction are
+    recomputed, not stored.  (The BVH — 32 B per box test, 16 B per sphere test — is read from the LDS copy, not from HBM.)"""
+    return ((16 if moving else 12) + 16 + 8) * st["rays"]
+
+
+def extend_bytes_survey(st):
+    """The survey's pricing of the same kernel: a 60-byte payload per ray (origin, direction, time, throughput, pixel and
+    generator state in one record).  Kept beside the figure above: this implementation moves less."""
     return 60 * st["rays"]
 
 
@@ -114,8 +122,12 @@ def other_configs(ctx, rrt_amd, torch, dev):
     out = []
     for name, kind, nx, ny, ns, half in (("book2chap2 moving spheres, 1200x800, 500 spp", rrt_amd.SCENE_BOOK2CHAP2, 1200, 800, 500, 11),
                                          ("1 M random spheres (2 M BVH nodes walked in HBM, two children per 64-byte record), 1920x1080, 256 spp", rrt_amd.SCENE_RANDOM_SPHERES, 1920, 1080, 256, 500)):
-        scene = rrt_amd.HostScene(kind, nx, ny, seed=SEED, half=half)
+        t0 = time.perf_counter()
+        scene = rrt_amd.HostScene(kind, nx, ny, seed=SEED, half=half)   # spheres on the host; the tree on the GPU for big scenes (Scene::build_bvh)
+        t_build = time.perf_counter() - t0
+        t0 = time.perf_counter()
         ctx.upload_host_scene(scene)
+        t_upload = time.perf_counter() - t0
         rgb = torch.zeros(ny * nx * 3, dtype=torch.uint8, device=dev)
         torch.cuda.synchronize()
         ctx.render_device(rrt_amd.Context.params(nx, ny, 4, seed=SEED), rgb.data_ptr(), 0)
@@ -132,6 +144,9 @@ def other_configs(ctx, rrt_amd, torch, dev):
         gbs = per_ray * st["rays"] / dt / 1e9
         entry = {"workload": name, "spheres": scene.n_spheres, "bvh_nodes": scene.n_nodes, "ms_per_step": round(dt * 1e3, 2),
                  "value": round(st["rays"] / dt / 1e6, 1), "unit": "Mrays/s", "rays_per_step": st["rays"],
+                 "setup_s": {"scene_and_bvh_build": round(t_build, 3), "layout_and_upload": round(t_upload, 3),
+                             "note": "before the timed step: the scene builder (sphere list on the host, Bvh::build on the GPU for scenes of "
+                                     "32 Ki spheres or more) and rrt_upload_scene (validation, traversal layout, copies to the device)"},
                  "per_ray": {"inner_visits": round(cst["inner_visits"] / cst["rays"], 2), "leaf_tests": round(cst["leaf_tests"] / cst["rays"], 2),
                              "algorithmic_bytes": round(per_ray, 1)}}
         if in_lds:
@@ -148,7 +163,7 @@ def other_configs(ctx, rrt_amd, torch, dev):
             if tr:
                 mb = tr["bytes_per_ray"]["total"] * st["rays"] / dt / 1e9
                 entry["hbm"] = {"achieved": round(mb, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(mb / HBM_PEAK_GBS, 4),
-                                "bytes_per_ray": tr["bytes_per_ray"], "extend": tr.get("extend"),
+                                "bytes_per_ray": tr["bytes_per_ray"], "extend": tr.get("extend"), "shade": tr.get("shade"),
                                 "note": "measured HBM bytes per ray of extend + shade (FETCH_SIZE x 2 + WRITE_SIZE, " + tr["source"] + ") x this run's rays / wall time"}
         out.append(entry)
         scene.close()
@@ -275,6 +290,7 @@ def main():
         if rank == 0 and ext_ms > 0:
             flops = extend_flops(cst) * args.steps
             byts = extend_bytes(cst) * args.steps
+            byts_survey = extend_bytes_survey(cst) * args.steps
             sec = ext_ms * 1e-3 * TIME_STRIDE          # the timed launches are every TIME_STRIDE-th one
             ext_launches *= TIME_STRIDE
             traffic = load_profile_json("extend_traffic.json")
@@ -298,7 +314,11 @@ def main():
                               "frac": round(job_flops(cst) * args.steps / elapsed / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 4),
                               "note": "all algorithmic FLOPs of a step (every kernel) over wall time, per GPU (rank 0's share)"},
                 "hbm": {"achieved": round(byts / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(byts / sec / 1e9 / HBM_PEAK_GBS, 4),
-                        "note": "extend kernel alone, over its summed (overlapping) launch durations"},
+                        "bytes_per_ray": round(byts / args.steps / cst["rays"], 1),
+                        "survey_pricing": {"bytes_per_ray": 60, "achieved": round(byts_survey / sec / 1e9, 1), "frac": round(byts_survey / sec / 1e9 / HBM_PEAK_GBS, 4)},
+                        "note": "extend kernel alone, over its summed (overlapping) launch durations; bytes as the kernel moves them "
+                                "(12 B origin + 16 B direction in, 8 B hit record out; measured: counters.bytes_per_ray.extend), the survey's "
+                                "60-byte payload beside it"},
                 "per_ray": {"inner_visits": round(cst["inner_visits"] / cst["rays"], 2), "leaf_tests": round(cst["leaf_tests"] / cst["rays"], 2),
                             "rays_per_path": round(cst["rays"] / cst["paths"], 3)},
             }
@@ -307,6 +327,7 @@ def main():
                 for key in ("valu_busy", "lane_util", "lds_conflict_frac"):
                     if key in counters.get("extend", {}):
                         roofline[key] = counters["extend"][key]
+                roofline["shade"] = {key: counters["shade"][key] for key in ("valu_busy", "lane_util", "lds_conflict_frac") if key in counters.get("shade", {})}
                 roofline["counters"] = counters
                 bpr = counters.get("bytes_per_ray")
                 if bpr:

@@ -232,6 +232,14 @@ RRT_API uint32_t rrt_shard_pixels(uint32_t nx, uint32_t ny, uint32_t shard_mode,
  * n <= 2^27 (the node index space of rrt_upload_scene).  Blocking. */
 RRT_API int rrt_build_bvh(rrt_ctx *ctx, const rrt_sphere_soa *spheres, rrt_bvh_node *out_nodes, uint32_t capacity, uint32_t *n_nodes);
 
+/* The same with the method of the top-level call (enum BvhPartitionMethod, src/acceleration.rs:98-103): RRT_BVH_MIDDLE is
+ * rrt_build_bvh; RRT_BVH_EQUAL_COUNT sorts every range by centroid[axis] and cuts it at len / 2 (src/acceleration.rs:186-194),
+ * ties in sorted order as a stable sort leaves them.  Either way the whole tree is built on the GPU, the equal-count
+ * subtrees of a Middle build included. */
+enum { RRT_BVH_MIDDLE = 0, RRT_BVH_EQUAL_COUNT = 1 };
+RRT_API int rrt_build_bvh_method(rrt_ctx *ctx, const rrt_sphere_soa *spheres, uint32_t method, rrt_bvh_node *out_nodes, uint32_t capacity,
+                                 uint32_t *n_nodes);
+
 /* Name, compute units and HBM bytes of the context's device. */
 RRT_API int rrt_device_info(rrt_ctx *ctx, char *name, size_t name_len, int *compute_units, uint64_t *hbm_bytes);
 

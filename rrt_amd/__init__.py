@@ -123,6 +123,7 @@ def lib() -> C.CDLL:
     L.rrt_validate_scene.argtypes = [C.POINTER(SphereSoa), C.POINTER(MaterialSoa), vp, u32]
     L.rrt_debug_layout.argtypes = [C.POINTER(SphereSoa), C.POINTER(MaterialSoa), vp, u32, vp, pu, pu]
     L.rrt_build_bvh.argtypes = [vp, C.POINTER(SphereSoa), vp, u32, pu]
+    L.rrt_build_bvh_method.argtypes = [vp, C.POINTER(SphereSoa), u32, vp, u32, pu]
     L.rrt_shard_pixels.argtypes = [u32, u32, u32, u32, u32, vp]
     L.rrt_shard_pixels.restype = u32
     L.rrt_device_info.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(i32), C.POINTER(u64)]
@@ -258,8 +259,9 @@ class Context:
     def upload_host_scene(self, scene: HostScene) -> None:
         _check(lib().rrt_host_scene_upload(scene.handle, self._h), "rrt_host_scene_upload")
 
-    def build_bvh(self, spheres9: np.ndarray) -> np.ndarray:
-        """rrt_build_bvh: the reference's Middle-split BVH over the spheres, built on the GPU; nodes [2n-1, 8] u32."""
+    def build_bvh(self, spheres9: np.ndarray, method: int = 0) -> np.ndarray:
+        """rrt_build_bvh_method: the reference's BVH over the spheres (method 0 = Middle, 1 = EqualCount), built on the GPU;
+        nodes [2n-1, 8] u32."""
         sp = np.ascontiguousarray(spheres9, np.float32)
         n = sp.shape[0]
         cols = [np.ascontiguousarray(sp[:, i]) for i in range(9)]
@@ -267,7 +269,7 @@ class Context:
         s = SphereSoa(*[_fptr(c) for c in cols], mid.ctypes.data_as(C.POINTER(C.c_uint32)), n)
         nodes = np.zeros((max(1, 2 * n - 1), 8), np.uint32)
         count = C.c_uint32(0)
-        _check(lib().rrt_build_bvh(self._h, C.byref(s), nodes.ctypes.data, nodes.shape[0], C.byref(count)), "rrt_build_bvh")
+        _check(lib().rrt_build_bvh_method(self._h, C.byref(s), method, nodes.ctypes.data, nodes.shape[0], C.byref(count)), "rrt_build_bvh")
         return nodes[:count.value]
 
     def upload_scene(self, spheres9: np.ndarray, material_id: np.ndarray, mats6: np.ndarray, nodes8: np.ndarray) -> None:

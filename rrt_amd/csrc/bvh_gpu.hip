@@ -12,8 +12,11 @@
 //     and every later split, does not depend on their order inside the side; here a stable partition by one prefix sum
 //     over the whole object array serves every open range of a level at once;
 //   * box and centroid bounds of a range are min/max reductions, exact in any order.
+//   * the equal-count split (:186-194) is "sort the range by centroid[axis], cut it in the middle": one stable radix sort
+//     of the whole object array by (start of the object's range, centroid[axis]) sorts every such range of a level at
+//     once and leaves everything else where it is.
 // A range whose Middle split leaves one side empty switches, with its whole subtree, to the equal-count split
-// (:180-193).  Those subtrees (identical centroids: rare and small) are finished on the host by the same rule.
+// (:180-183); a build can also ask for equal counts from the root down (BvhPartitionMethod::EqualCount).
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
@@ -35,6 +38,7 @@ struct ObjBox { float mn[3], mx[3], c[3]; };
 
 struct Seg {  // an open range of the current level
     uint32_t start, count, node;
+    uint32_t equal;  // split by equal counts (asked for, or inherited from an ancestor whose Middle split failed)
 };
 
 struct SegWork {
@@ -44,7 +48,7 @@ struct SegWork {
     uint32_t scan_at_start;
     uint32_t left_seg, right_seg;    // index in the next level's list, or kClosed
     uint32_t left_node, right_node;  // node index of a child
-    uint32_t split;                  // 0: the range left the GPU build (equal-count fallback)
+    uint32_t equal;                  // this range is cut by equal counts (its objects are taken from the sorted order)
 };
 
 __host__ __device__ inline uint32_t enc(float f) {
@@ -140,12 +144,12 @@ __global__ void k_decide(uint32_t n_seg, const Seg *segs, SegWork *work, rrt_bvh
     for (int k = 0; k < 3; k++) { nd.min[k] = dec(w.box_mn[k]); nd.max[k] = dec(w.box_mx[k]); }
 }
 
-__global__ void k_side(uint32_t n, const uint32_t *seg_id, const uint32_t *order, const ObjBox *boxes, SegWork *work, uint32_t *flag) {
+__global__ void k_side(uint32_t n, const uint32_t *seg_id, const uint32_t *order, const Seg *segs, const ObjBox *boxes, SegWork *work, uint32_t *flag) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t s = seg_id[i];
     uint32_t left = 0;
-    if (s != kClosed) {
+    if (s != kClosed && !segs[s].equal) {
         left = boxes[order[i]].c[work[s].axis] < work[s].mid ? 1u : 0u;  // :176
         if (left) atomicAdd(&work[s].n_left, 1u);
     }
@@ -153,39 +157,57 @@ __global__ void k_side(uint32_t n, const uint32_t *seg_id, const uint32_t *order
 }
 
 __global__ void k_split(uint32_t n_seg, const Seg *segs, SegWork *work, const uint32_t *scan, rrt_bvh_node *nodes, Seg *next, uint32_t *n_next,
-                        Seg *fallback, uint32_t *n_fallback) {
+                        uint32_t *n_equal) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_seg) return;
     SegWork &w = work[s];
     const Seg g = segs[s];
     w.scan_at_start = scan[g.start];
-    if (w.n_left == 0u || w.n_left == g.count) {  // :180-183: equal counts from here down, finished on the host
-        w.split = 0u;
-        fallback[atomicAdd(n_fallback, 1u)] = g;
-        return;
-    }
-    w.split = 1u;
+    const bool equal = g.equal != 0u || w.n_left == 0u || w.n_left == g.count;  // :180-183: equal counts from here down
+    w.equal = equal ? 1u : 0u;
+    if (equal) { w.n_left = g.count / 2u; atomicAdd(n_equal, 1u); }  // :187
     const uint32_t nl = w.n_left, nr = g.count - nl;
     w.left_node = g.node + 1u;
     w.right_node = g.node + 2u * nl;
     nodes[g.node].left_or_obj = w.left_node;
     nodes[g.node].right_axis_leaf = w.right_node | (w.axis << RRT_NODE_AXIS_SHIFT);
-    if (nl >= 2u) { w.left_seg = atomicAdd(n_next, 1u); next[w.left_seg] = Seg{g.start, nl, w.left_node}; }
-    if (nr >= 2u) { w.right_seg = atomicAdd(n_next, 1u); next[w.right_seg] = Seg{g.start + nl, nr, w.right_node}; }
+    if (nl >= 2u) { w.left_seg = atomicAdd(n_next, 1u); next[w.left_seg] = Seg{g.start, nl, w.left_node, w.equal}; }
+    if (nr >= 2u) { w.right_seg = atomicAdd(n_next, 1u); next[w.right_seg] = Seg{g.start + nl, nr, w.right_node, w.equal}; }
 }
 
-// the stable partition of every open range, and the leaves of the ranges that are down to one object
-__global__ void k_scatter(uint32_t n, const uint32_t *seg_id, const uint32_t *order, const Seg *segs, const SegWork *work, const uint32_t *scan,
-                          const uint32_t *flag, uint32_t *order_next, uint32_t *seg_next, rrt_bvh_node *nodes) {
+// Sort keys of a level with equal-count ranges: (start of the range, centroid along the range's axis) for their objects,
+// (own position, 0) for everything else, so that one stable sort of the whole array sorts each such range in place.
+__global__ void k_sort_keys(uint32_t n, const uint32_t *seg_id, const uint32_t *order, const Seg *segs, const SegWork *work, const ObjBox *boxes, uint64_t *keys) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t s = seg_id[i], obj = order[i];
-    if (s == kClosed || !work[s].split) { order_next[i] = obj; seg_next[i] = kClosed; return; }
+    const uint32_t s = seg_id[i];
+    uint64_t k = (uint64_t)i << 32;
+    if (s != kClosed && work[s].equal) k = ((uint64_t)segs[s].start << 32) | enc(boxes[order[i]].c[work[s].axis]);
+    keys[i] = k;
+}
+
+// the stable partition (or the cut of the sorted order) of every open range, and the leaves of the ranges that are down to
+// one object
+__global__ void k_scatter(uint32_t n, const uint32_t *seg_id, const uint32_t *order, const uint32_t *order_sorted, const Seg *segs, const SegWork *work,
+                          const uint32_t *scan, const uint32_t *flag, uint32_t *order_next, uint32_t *seg_next, rrt_bvh_node *nodes) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = seg_id[i];
+    if (s == kClosed) { order_next[i] = order[i]; seg_next[i] = kClosed; return; }
     const SegWork &w = work[s];
     const Seg g = segs[s];
-    const uint32_t lefts_before = scan[i] - w.scan_at_start;
-    const bool left = flag[i] != 0u;
-    const uint32_t pos = left ? g.start + lefts_before : g.start + w.n_left + ((i - g.start) - lefts_before);
+    uint32_t obj, pos;
+    bool left;
+    if (w.equal) {  // position i of the range, in sorted order (:188-193)
+        obj = order_sorted[i];
+        pos = i;
+        left = i - g.start < w.n_left;
+    } else {
+        obj = order[i];
+        const uint32_t lefts_before = scan[i] - w.scan_at_start;
+        left = flag[i] != 0u;
+        pos = left ? g.start + lefts_before : g.start + w.n_left + ((i - g.start) - lefts_before);
+    }
     const uint32_t child_seg = left ? w.left_seg : w.right_seg;
     order_next[pos] = obj;
     seg_next[pos] = child_seg;
@@ -196,37 +218,6 @@ __global__ void k_scatter(uint32_t n, const uint32_t *seg_id, const uint32_t *or
         leaf.right_axis_leaf = RRT_NODE_LEAF_BIT;
         nodes[left ? w.left_node : w.right_node] = leaf;
     }
-}
-
-// ---- the equal-count rule on the host, for the ranges the GPU build handed back (rrt.cpp: Bvh::build_r, EqualCount) ----
-struct HostObj { ObjBox b; uint32_t id; };
-
-void build_equal_count(HostObj *o, size_t n, uint32_t node, rrt_bvh_node *nodes) {
-    if (n == 1) {
-        rrt_bvh_node leaf{};
-        leaf.left_or_obj = o[0].id;
-        leaf.right_axis_leaf = RRT_NODE_LEAF_BIT;
-        nodes[node] = leaf;
-        return;
-    }
-    float bmn[3] = {kFltMax, kFltMax, kFltMax}, bmx[3] = {-kFltMax, -kFltMax, -kFltMax};
-    float cmn[3] = {kFltMax, kFltMax, kFltMax}, cmx[3] = {-kFltMax, -kFltMax, -kFltMax};
-    for (size_t i = 0; i < n; i++)
-        for (int k = 0; k < 3; k++) {
-            bmn[k] = std::min(bmn[k], o[i].b.mn[k]); bmx[k] = std::max(bmx[k], o[i].b.mx[k]);
-            cmn[k] = std::min(cmn[k], o[i].b.c[k]); cmx[k] = std::max(cmx[k], o[i].b.c[k]);
-        }
-    const float dx = cmx[0] - cmn[0], dy = cmx[1] - cmn[1], dz = cmx[2] - cmn[2];
-    const int axis = (dx > dy && dx > dz) ? 0 : (dy > dz ? 1 : 2);
-    const size_t pivot = n / 2;
-    std::stable_sort(o, o + n, [&](const HostObj &a, const HostObj &b) { return a.b.c[axis] < b.b.c[axis]; });
-    rrt_bvh_node inner{};
-    for (int k = 0; k < 3; k++) { inner.min[k] = bmn[k]; inner.max[k] = bmx[k]; }
-    inner.left_or_obj = node + 1u;
-    inner.right_axis_leaf = (node + 2u * (uint32_t)pivot) | ((uint32_t)axis << RRT_NODE_AXIS_SHIFT);
-    nodes[node] = inner;
-    build_equal_count(o, pivot, node + 1u, nodes);
-    build_equal_count(o + pivot, n - pivot, node + 2u * (uint32_t)pivot, nodes);
 }
 
 struct Buf {
@@ -244,7 +235,7 @@ struct Buf {
         if (e_ != hipSuccess) { err = std::string(#expr) + ": " + hipGetErrorString(e_); return RRT_ERR_HIP; } \
     } while (0)
 
-int gpu_build_bvh(hipStream_t st, const rrt_sphere_soa *sp, rrt_bvh_node *out_nodes, uint32_t capacity, uint32_t *n_nodes, std::string &err) {
+int gpu_build_bvh(hipStream_t st, const rrt_sphere_soa *sp, uint32_t method, rrt_bvh_node *out_nodes, uint32_t capacity, uint32_t *n_nodes, std::string &err) {
     const uint32_t n = sp->n;
     const uint32_t total = 2u * n - 1u;
     if (capacity < total) { err = "rrt_build_bvh: out_nodes holds fewer than 2n-1 nodes"; return RRT_ERR_INVALID_ARGUMENT; }
@@ -254,7 +245,7 @@ int gpu_build_bvh(hipStream_t st, const rrt_sphere_soa *sp, rrt_bvh_node *out_no
         out_nodes[0] = leaf; *n_nodes = 1;
         return RRT_OK;
     }
-    Buf planes[7], boxes, order[2], seg_id[2], flag, scan, segs[2], work, nodes, counters, fallback, cub_tmp;
+    Buf planes[7], boxes, order[2], seg_id[2], flag, scan, segs[2], work, nodes, counters, cub_tmp, keys[2], order_sorted;
     const float *src[7] = {sp->c0x, sp->c0y, sp->c0z, sp->c1x, sp->c1y, sp->c1z, sp->radius};
     for (int k = 0; k < 7; k++) {
         BVH_TRY(planes[k].alloc((size_t)n * 4));
@@ -265,63 +256,62 @@ int gpu_build_bvh(hipStream_t st, const rrt_sphere_soa *sp, rrt_bvh_node *out_no
     BVH_TRY(flag.alloc((size_t)n * 4)); BVH_TRY(scan.alloc((size_t)n * 4));
     BVH_TRY(work.alloc((size_t)n * sizeof(SegWork)));
     BVH_TRY(nodes.alloc((size_t)total * sizeof(rrt_bvh_node)));
-    BVH_TRY(counters.alloc(8)); BVH_TRY(fallback.alloc((size_t)n * sizeof(Seg)));
-    size_t tmp_bytes = 0;
+    BVH_TRY(counters.alloc(8));
+    size_t tmp_bytes = 0, sort_bytes = 0;
     BVH_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, flag.as<uint32_t>(), scan.as<uint32_t>(), (int)n, st));
-    BVH_TRY(cub_tmp.alloc(tmp_bytes));
+    // (the sort's buffers are made when a level first needs them: a Middle build of distinct centroids never does)
+    bool sort_ready = false;
 
     const dim3 blk(256), grid_n((n + 255u) / 256u);
     hipLaunchKernelGGL(k_prepare, grid_n, blk, 0, st, n, planes[0].as<float>(), planes[1].as<float>(), planes[2].as<float>(), planes[3].as<float>(),
                        planes[4].as<float>(), planes[5].as<float>(), planes[6].as<float>(), boxes.as<ObjBox>(), order[0].as<uint32_t>(),
                        seg_id[0].as<uint32_t>());
-    const Seg root{0u, n, 0u};
+    const Seg root{0u, n, 0u, method == RRT_BVH_EQUAL_COUNT ? 1u : 0u};
     BVH_TRY(hipMemcpyAsync(segs[0].p, &root, sizeof(Seg), hipMemcpyHostToDevice, st));
-    uint32_t *n_next = counters.as<uint32_t>(), *n_fallback = counters.as<uint32_t>() + 1;
-    BVH_TRY(hipMemsetAsync(counters.p, 0, 8, st));
+    uint32_t *n_next = counters.as<uint32_t>(), *n_equal = counters.as<uint32_t>() + 1;
+    BVH_TRY(cub_tmp.alloc(tmp_bytes));
 
     uint32_t n_seg = 1;
     int cur = 0;
     for (uint32_t level = 0; n_seg != 0u; level++) {
         if (level > n) { err = "rrt_build_bvh: level loop did not terminate"; return RRT_ERR_HIP; }
         const dim3 grid_s((n_seg + 255u) / 256u);
-        BVH_TRY(hipMemsetAsync(n_next, 0, 4, st));
+        BVH_TRY(hipMemsetAsync(counters.p, 0, 8, st));
         hipLaunchKernelGGL(k_init_work, grid_s, blk, 0, st, n_seg, work.as<SegWork>());
         hipLaunchKernelGGL(k_bounds, grid_n, blk, 0, st, n, seg_id[cur].as<uint32_t>(), order[cur].as<uint32_t>(), boxes.as<ObjBox>(), work.as<SegWork>());
         hipLaunchKernelGGL(k_decide, grid_s, blk, 0, st, n_seg, segs[cur].as<Seg>(), work.as<SegWork>(), nodes.as<rrt_bvh_node>());
-        hipLaunchKernelGGL(k_side, grid_n, blk, 0, st, n, seg_id[cur].as<uint32_t>(), order[cur].as<uint32_t>(), boxes.as<ObjBox>(), work.as<SegWork>(),
-                           flag.as<uint32_t>());
+        hipLaunchKernelGGL(k_side, grid_n, blk, 0, st, n, seg_id[cur].as<uint32_t>(), order[cur].as<uint32_t>(), segs[cur].as<Seg>(), boxes.as<ObjBox>(),
+                           work.as<SegWork>(), flag.as<uint32_t>());
         BVH_TRY(hipcub::DeviceScan::ExclusiveSum(cub_tmp.p, tmp_bytes, flag.as<uint32_t>(), scan.as<uint32_t>(), (int)n, st));
         hipLaunchKernelGGL(k_split, grid_s, blk, 0, st, n_seg, segs[cur].as<Seg>(), work.as<SegWork>(), scan.as<uint32_t>(), nodes.as<rrt_bvh_node>(),
-                           segs[cur ^ 1].as<Seg>(), n_next, fallback.as<Seg>(), n_fallback);
-        hipLaunchKernelGGL(k_scatter, grid_n, blk, 0, st, n, seg_id[cur].as<uint32_t>(), order[cur].as<uint32_t>(), segs[cur].as<Seg>(),
-                           work.as<SegWork>(), scan.as<uint32_t>(), flag.as<uint32_t>(), order[cur ^ 1].as<uint32_t>(), seg_id[cur ^ 1].as<uint32_t>(),
-                           nodes.as<rrt_bvh_node>());
+                           segs[cur ^ 1].as<Seg>(), n_next, n_equal);
         BVH_TRY(hipGetLastError());
-        BVH_TRY(hipMemcpyAsync(&n_seg, n_next, 4, hipMemcpyDeviceToHost, st));
+        uint32_t got[2] = {0, 0};  // ranges of the next level; ranges of this one cut by equal counts
+        BVH_TRY(hipMemcpyAsync(got, counters.p, 8, hipMemcpyDeviceToHost, st));
         BVH_TRY(hipStreamSynchronize(st));
+        if (got[1] != 0u) {
+            if (!sort_ready) {
+                BVH_TRY(keys[0].alloc((size_t)n * 8)); BVH_TRY(keys[1].alloc((size_t)n * 8)); BVH_TRY(order_sorted.alloc((size_t)n * 4));
+                BVH_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys[0].as<uint64_t>(), keys[1].as<uint64_t>(), order[0].as<uint32_t>(),
+                                                           order_sorted.as<uint32_t>(), (int)n, 0, 64, st));
+                if (sort_bytes > tmp_bytes) { Buf bigger; BVH_TRY(bigger.alloc(sort_bytes)); std::swap(bigger.p, cub_tmp.p); tmp_bytes = sort_bytes; }
+                sort_ready = true;
+            }
+            hipLaunchKernelGGL(k_sort_keys, grid_n, blk, 0, st, n, seg_id[cur].as<uint32_t>(), order[cur].as<uint32_t>(), segs[cur].as<Seg>(), work.as<SegWork>(),
+                               boxes.as<ObjBox>(), keys[0].as<uint64_t>());
+            size_t bytes = tmp_bytes;
+            BVH_TRY(hipcub::DeviceRadixSort::SortPairs(cub_tmp.p, bytes, keys[0].as<uint64_t>(), keys[1].as<uint64_t>(), order[cur].as<uint32_t>(),
+                                                       order_sorted.as<uint32_t>(), (int)n, 0, 64, st));
+        }
+        hipLaunchKernelGGL(k_scatter, grid_n, blk, 0, st, n, seg_id[cur].as<uint32_t>(), order[cur].as<uint32_t>(),
+                           got[1] != 0u ? order_sorted.as<uint32_t>() : order[cur].as<uint32_t>(), segs[cur].as<Seg>(), work.as<SegWork>(), scan.as<uint32_t>(),
+                           flag.as<uint32_t>(), order[cur ^ 1].as<uint32_t>(), seg_id[cur ^ 1].as<uint32_t>(), nodes.as<rrt_bvh_node>());
+        BVH_TRY(hipGetLastError());
+        n_seg = got[0];
         cur ^= 1;
     }
     BVH_TRY(hipMemcpyAsync(out_nodes, nodes.p, (size_t)total * sizeof(rrt_bvh_node), hipMemcpyDeviceToHost, st));
-    uint32_t n_fb = 0;
-    BVH_TRY(hipMemcpyAsync(&n_fb, n_fallback, 4, hipMemcpyDeviceToHost, st));
     BVH_TRY(hipStreamSynchronize(st));
-    if (n_fb) {
-        std::vector<Seg> fb(n_fb);
-        std::vector<uint32_t> ord(n);
-        BVH_TRY(hipMemcpy(fb.data(), fallback.p, (size_t)n_fb * sizeof(Seg), hipMemcpyDeviceToHost));
-        BVH_TRY(hipMemcpy(ord.data(), order[cur].p, (size_t)n * 4, hipMemcpyDeviceToHost));
-        std::vector<HostObj> objs;
-        for (const Seg &g : fb) {
-            objs.resize(g.count);
-            for (uint32_t k = 0; k < g.count; k++) {
-                const uint32_t id = ord[g.start + k];
-                const float c0[3] = {sp->c0x[id], sp->c0y[id], sp->c0z[id]}, c1[3] = {sp->c1x[id], sp->c1y[id], sp->c1z[id]};
-                objs[k].b = object_box(c0, c1, sp->radius[id]);
-                objs[k].id = id;
-            }
-            build_equal_count(objs.data(), objs.size(), g.node, out_nodes);
-        }
-    }
     *n_nodes = total;
     return RRT_OK;
 }

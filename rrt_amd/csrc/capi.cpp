@@ -18,7 +18,7 @@
 using namespace rrt_amd;
 
 namespace rrt_amd {
-int gpu_build_bvh(hipStream_t st, const rrt_sphere_soa *sp, rrt_bvh_node *out_nodes, uint32_t capacity, uint32_t *n_nodes, std::string &err);
+int gpu_build_bvh(hipStream_t st, const rrt_sphere_soa *sp, uint32_t method, rrt_bvh_node *out_nodes, uint32_t capacity, uint32_t *n_nodes, std::string &err);
 // noalloc.hip: address and size of the current device's copy of the library's static workspace
 int static_workspace(int device, void **ptr, size_t *bytes, std::string &err);
 // for noalloc.hip: a render call that takes all its device memory from `workspace`
@@ -590,7 +590,12 @@ int render_queued(rrt_ctx *c, const rrt_render_params &P, const RenderTarget &T,
 extern "C" {
 
 int rrt_build_bvh(rrt_ctx *c, const rrt_sphere_soa *sp, rrt_bvh_node *out_nodes, uint32_t capacity, uint32_t *n_nodes) {
+    return rrt_build_bvh_method(c, sp, RRT_BVH_MIDDLE, out_nodes, capacity, n_nodes);
+}
+
+int rrt_build_bvh_method(rrt_ctx *c, const rrt_sphere_soa *sp, uint32_t method, rrt_bvh_node *out_nodes, uint32_t capacity, uint32_t *n_nodes) {
     if (!c || !sp || !out_nodes || !n_nodes) return fail(RRT_ERR_INVALID_ARGUMENT, "rrt_build_bvh: null argument");
+    if (method > RRT_BVH_EQUAL_COUNT) return fail(RRT_ERR_INVALID_ARGUMENT, "rrt_build_bvh: unknown partition method");
     if (sp->n == 0) return fail(RRT_ERR_BAD_SCENE, "rrt_build_bvh: no objects (Bvh::build of an empty scene yields no nodes)");
     if (sp->n > (kRefIndexMask + 1u) / 2u) return fail(RRT_ERR_BAD_SCENE, "rrt_build_bvh: too many objects");  // 2n-1 nodes must fit rrt_upload_scene
     if (!sp->c0x || !sp->c0y || !sp->c0z || !sp->c1x || !sp->c1y || !sp->c1z || !sp->radius)
@@ -598,7 +603,7 @@ int rrt_build_bvh(rrt_ctx *c, const rrt_sphere_soa *sp, rrt_bvh_node *out_nodes,
     HIP_TRY(hipSetDevice(c->device));
     try {
         std::string err;
-        const int rc = rrt_amd::gpu_build_bvh(c->stream, sp, out_nodes, capacity, n_nodes, err);
+        const int rc = rrt_amd::gpu_build_bvh(c->stream, sp, method, out_nodes, capacity, n_nodes, err);
         return rc == RRT_OK ? rc : fail(rc, err);
     } catch (const std::exception &e) { return fail(RRT_ERR_OUT_OF_MEMORY, std::string("rrt_build_bvh: ") + e.what()); }
 }

@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 
@@ -193,7 +194,49 @@ std::vector<const Hittable *> Scene::objects() const {
     for (const Sphere &s : spheres) v.push_back(&s);
     return v;
 }
-void Scene::build_bvh(BvhPartitionMethod method) { bvh.build(objects(), method); }
+namespace {
+// One context for tree builds, made on first use on the current device and kept (null if there is no device).
+rrt_ctx *build_context() {
+    static std::mutex mu;
+    static bool tried = false;
+    static rrt_ctx *ctx = nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!tried) {
+        tried = true;
+        if (rrt_create(-1, &ctx) != RRT_OK) ctx = nullptr;
+    }
+    return ctx;
+}
+}  // namespace
+
+void Scene::build_bvh(BvhPartitionMethod method) {
+    const char *host_only = std::getenv("RRT_HOST_BVH");
+    if (spheres.size() >= kGpuBuildMinSpheres && !(host_only && host_only[0] == '1')) {
+        if (rrt_ctx *ctx = build_context()) {
+            const size_t n = spheres.size();
+            std::vector<float> plane[7];
+            for (auto &v : plane) v.resize(n);
+            for (size_t i = 0; i < n; i++) {
+                const Sphere &s = spheres[i];
+                plane[0][i] = s.center0().x; plane[1][i] = s.center0().y; plane[2][i] = s.center0().z;
+                plane[3][i] = s.center1().x; plane[4][i] = s.center1().y; plane[5][i] = s.center1().z;
+                plane[6][i] = s.radius();
+            }
+            rrt_sphere_soa sp{};
+            sp.c0x = plane[0].data(); sp.c0y = plane[1].data(); sp.c0z = plane[2].data();
+            sp.c1x = plane[3].data(); sp.c1y = plane[4].data(); sp.c1z = plane[5].data();
+            sp.radius = plane[6].data();
+            sp.n = static_cast<uint32_t>(n);
+            std::vector<rrt_bvh_node> nodes(2 * n - 1);
+            uint32_t n_nodes = 0;
+            const int rc = rrt_build_bvh_method(ctx, &sp, method == BvhPartitionMethod::EqualCount ? RRT_BVH_EQUAL_COUNT : RRT_BVH_MIDDLE, nodes.data(),
+                                                static_cast<uint32_t>(nodes.size()), &n_nodes);
+            if (rc == RRT_OK && n_nodes == nodes.size()) { bvh.adopt(std::move(nodes)); return; }
+            // (a failed device build — out of device memory, say — is not an error of the scene: the host builds the same tree)
+        }
+    }
+    bvh.build(objects(), method);
+}
 
 // ------------------------------------------------------------------ Camera (camera.rs:31-54)
 namespace {

@@ -673,16 +673,24 @@ def test_full_size_image_digests(gpu_ctx, name):
     assert_matches_fullsize_digest(name, rgb, acc, st)
 
 
+@pytest.mark.parametrize("method", [0, 1])   # BvhPartitionMethod::Middle, ::EqualCount (acceleration.rs:98-103)
 @pytest.mark.parametrize("kind,half", [(rrt_amd.SCENE_CHAP11, 0), (rrt_amd.SCENE_CHAP12, 0), (rrt_amd.SCENE_BOOK2CHAP2, 0),
                                        (rrt_amd.SCENE_RANDOM_SPHERES, 60), (rrt_amd.SCENE_RANDOM_SPHERES, 500)])
-def test_gpu_bvh_build_is_the_reference_tree(gpu_ctx, kind, half):
-    """rrt_build_bvh (level-synchronous, on the device) against the oracle's recursive Bvh::build_r restatement: every node,
-    every bit.  chap11 takes the equal-count fallback (two concentric spheres), book2chap2 has moving boxes."""
+def test_gpu_bvh_build_is_the_reference_tree(gpu_ctx, kind, half, method):
+    """rrt_build_bvh_method (level-synchronous, on the device) against the oracle's recursive Bvh::build_r restatement: every
+    node, every bit, for both partition methods.  chap11 takes the equal-count fallback of a Middle build (two concentric
+    spheres), book2chap2 has moving boxes."""
     osc = OracleScene.build(kind, 64, 64, seed=0, half=max(half, 11))
+    if method:
+        osc.build_bvh(method)
     sp, mt, nd, _ = osc.export()
-    got = gpu_ctx.build_bvh(sp)
+    got = gpu_ctx.build_bvh(sp, method)
     assert got.shape == nd.shape
     assert np.array_equal(got, nd), f"{int((got != nd).any(axis=1).sum())} of {nd.shape[0]} nodes differ"
+    if method and half <= 60:   # an equal-count tree renders like any other
+        gpu_ctx.upload_scene(sp, np.arange(sp.shape[0], dtype=np.uint32), mt, got)
+        gpu_ctx.set_camera(rrt_amd.Camera.from_buffer_copy(scene_arrays_from_oracle(osc)[4].tobytes()))
+        assert_same_image(gpu_ctx.render(rrt_amd.Context.params(48, 32, 3, seed=2)), osc.render(48, 32, 3, seed=2, threads=8))
 
 
 def test_gpu_bvh_build_degenerate_inputs(gpu_ctx):
@@ -707,10 +715,11 @@ def test_gpu_bvh_build_degenerate_inputs(gpu_ctx):
         n = sp.shape[0]
         mt = np.zeros((n, 6), np.float32); mt[:, 1:4] = 0.5
         osc = O.from_arrays(sp, np.arange(n, dtype=np.uint32), mt, np.zeros((1, 8), np.uint32))
-        osc.build_bvh(0)
-        _, _, nd, _ = osc.export()
-        got = gpu_ctx.build_bvh(sp)
-        assert got.shape == nd.shape and np.array_equal(got, nd), f"n={n}: {int((got != nd).any(axis=1).sum())} nodes differ"
+        for method in (0, 1):
+            osc.build_bvh(method)
+            _, _, nd, _ = osc.export()
+            got = gpu_ctx.build_bvh(sp, method)
+            assert got.shape == nd.shape and np.array_equal(got, nd), f"n={n} method {method}: {int((got != nd).any(axis=1).sum())} nodes differ"
 
 
 def test_device_buffer_entry_points(gpu_ctx):
