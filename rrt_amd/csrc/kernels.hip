@@ -25,6 +25,8 @@ namespace {
 DEV float u2f(uint32_t u) { return __uint_as_float(u); }
 DEV uint32_t f2u(float f) { return __float_as_uint(f); }
 DEV uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+// how many lanes below this one are set in a ballot (v_mbcnt_lo/hi: no per-lane mask to keep)
+DEV uint32_t prefix_count(uint64_t m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));  // one v_pk_* operand
 
@@ -645,7 +647,6 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
     uint32_t slot = 0;
     bool has = false;
     uint32_t head = 0;  // first list position not handed out yet (wave-uniform)
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
     RayCtx r;
     typename Store::Stack stk;
     uint2 stack_spill[Store::kSpillEntries];  // (two-children walk) stack positions beyond those that LDS holds
@@ -667,7 +668,7 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
                 if (lane == 0) got = atomicAdd(pool_head, n_idle);
                 head = min(rfl(got), count);
             }
-            const uint32_t pos = head + (uint32_t)__popcll(idle_m & lt_mask);
+            const uint32_t pos = head + prefix_count(idle_m);
             uint32_t n_slot = base + pos;  // the pool, or a full list, is a run of consecutive slots
             if (!pooled && count != kWaveSlots) {  // list entry p sits in lane p % 64, register p / 64
                 const uint32_t col = pos >> 6;
@@ -911,7 +912,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_raygen(PathState P, BatchDev 
         const uint32_t slot = base + t0 + lane;
         const bool alive = start_path(P, Bt, C, shard, base_n + t0 + lane, slot, (P.layout & kLayoutTimed) != 0u, (P.layout & kLayoutNarrow) != 0u);
         const uint64_t am = __ballot(alive);
-        if (alive) P.queue[base + out_count + (uint32_t)__popcll(am & ((1ull << lane) - 1ull))] = slot;
+        if (alive) P.queue[base + out_count + prefix_count(am)] = slot;
         out_count += (uint32_t)__popcll(am);
     }
     if (lane == 0) {
@@ -1195,7 +1196,6 @@ DEV uint32_t shade_wave(const SceneDev &S, const PathState &P, const BatchDev &B
     const uint32_t base = wave * kWaveSlots;
     uint32_t *l_slot = reinterpret_cast<uint32_t *>(l_ent);
     const uint32_t shard = wave % Bt.n_shards;
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
     static_assert(kWaveSlots == 256, "four list entries per lane");
 
 #ifdef RRT_SHADE_TIMING
@@ -1308,7 +1308,7 @@ DEV uint32_t shade_wave(const SceneDev &S, const PathState &P, const BatchDev &B
             // ending slots take the claimed path ids in list order
             const bool ending = cls == CL_SKY || cls == CL_CUT;
             const uint64_t end_m = __ballot(ending);
-            const uint32_t end_rank = end_before[t] + (uint32_t)__popcll(end_m & lt_mask);
+            const uint32_t end_rank = end_before[t] + prefix_count(end_m);
             const uint32_t end_hi = end_before[t] + (uint32_t)__popcll(end_m);
             NewPath np;  // read by the lanes of ending slots only, and those always fetch one below
             np.ok = false;
@@ -1370,7 +1370,7 @@ DEV uint32_t shade_wave(const SceneDev &S, const PathState &P, const BatchDev &B
     for (uint32_t t = 0; t < 4u; t++) {
         const bool need = (absorbed_bits >> t) & 1u;
         const uint64_t nm = __ballot(need);
-        rank[t] = n_need + (uint32_t)__popcll(nm & lt_mask);
+        rank[t] = n_need + prefix_count(nm);
         if (need) l_slot[rank[t]] = sq[t];
         n_need += (uint32_t)__popcll(nm);
     }
@@ -1402,7 +1402,7 @@ DEV uint32_t shade_wave(const SceneDev &S, const PathState &P, const BatchDev &B
         uint32_t at = 0;
 #pragma unroll
         for (uint32_t t = 0; t < 4u; t++) {
-            if ((am[t] >> lane) & 1ull) P.queue[base + at + (uint32_t)__popcll(am[t] & lt_mask)] = sq[t];
+            if ((am[t] >> lane) & 1ull) P.queue[base + at + prefix_count(am[t])] = sq[t];
             at += (uint32_t)__popcll(am[t]);
         }
     }
