@@ -192,8 +192,11 @@ RRT_API int rrt_render_device(rrt_ctx *ctx, const rrt_render_params *params, voi
  * Limits, rejected with RRT_ERR_INVALID_ARGUMENT: nx*ny <= 512*512, max_depth <= 64, path_slots <= 16384
  * (0 = 16384), shard_mode NONE or SAMPLE, no kernel timing (reserved[0] is ignored).  Same image, bit for
  * bit, as rrt_render_device (scenes too big for LDS are walked along exit links here: the default walk of such scenes
- * keeps a stack in scratch memory, which the runtime allocates when its kernel is first launched).  All calls on one GPU share that GPU's array: calls that overlap on one GPU
- * (two contexts, two threads) race; calls one after another do not, each clears what it needs. */
+ * keeps a stack in scratch memory, which the runtime allocates when its kernel is first launched; rrt_create runs one small
+ * kernel with a private segment larger than any kernel's that this entry point launches on each of the context's streams,
+ * so that the runtime sizes their scratch memory there and not inside a call of this entry point).  All calls on one GPU
+ * share that GPU's array: calls that overlap on one GPU (two contexts, two threads) race; calls one after another do not,
+ * each clears what it needs. */
 #define RRT_NOALLOC_WORKSPACE_BYTES (16u << 20)
 RRT_API int rrt_render_device_noalloc(rrt_ctx *ctx, const rrt_render_params *params, void *d_rgb8, void *d_accum,
                                       rrt_stats *stats);

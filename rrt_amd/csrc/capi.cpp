@@ -166,6 +166,13 @@ int rrt_create(int device, rrt_ctx **out) {
         rrt_destroy(c);
         return fail(RRT_ERR_HIP, "rrt_create: " + err);
     }
+    // every stream a render may launch on gets its scratch memory sized here, where allocating is allowed (kernels.h)
+    launch_prime_scratch(c->stream, static_cast<uint32_t *>(c->scratch));
+    for (hipStream_t ss : c->side_stream) launch_prime_scratch(ss, static_cast<uint32_t *>(c->scratch));
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        rrt_destroy(c);
+        return fail(RRT_ERR_HIP, "rrt_create: the first kernel launch on the device failed");
+    }
     *out = c;
     return RRT_OK;
 }

@@ -105,6 +105,9 @@ struct BatchDev {
     uint32_t *alive_flag;      // null, or 32 words 128 bytes apart: a wave that still owns live paths after shading sets one
 };
 
+// One launch of a kernel with a 256-byte private segment: makes the runtime size the stream's scratch memory now rather
+// than at the first render kernel that reserves any (for the entry point that must allocate nothing while it runs)
+void launch_prime_scratch(hipStream_t s, uint32_t *any_device_word);
 void launch_raygen(hipStream_t s, const PathState &P, const BatchDev &B, const CameraDev &C, uint64_t *wave_stats);
 void launch_extend(hipStream_t s, const SceneDev &S, const PathState &P, bool moving, bool count, uint32_t retire_min,
                    uint32_t leaf_min, uint64_t *wave_stats);

@@ -1594,7 +1594,22 @@ __global__ void k_reduce_stats(const uint64_t *wave_stats, uint32_t n_waves, uin
 
 inline uint32_t wave_grid(const PathState &P) { return (P.wave_end - P.wave_begin + 3u) / 4u; }
 
+// A kernel whose only purpose is its private segment: 256 bytes per lane, more than any kernel of the render path that the
+// no-allocation entry point can launch reserves (the moving-sphere shade variant's descriptor asks for 36, the frame slots
+// of scalar registers it keeps in vector-register lanes).  The runtime sizes a queue's scratch memory when a kernel that
+// needs more than the queue has is first dispatched on it; launched once per stream at context creation, this one makes
+// that happen there.
+__global__ void k_prime_scratch(uint32_t *out, uint32_t n) {
+    volatile uint32_t a[64];
+    for (uint32_t i = 0; i < 64u; i++) a[i] = i * n;
+    uint32_t v = 0;
+    for (uint32_t i = 0; i < n; i++) v += a[(v + i * 7u) & 63u];
+    if (v == 0xFFFFFFFFu) out[0] = v;
+}
+
 }  // namespace
+
+void launch_prime_scratch(hipStream_t s, uint32_t *any_device_word) { hipLaunchKernelGGL(k_prime_scratch, dim3(1), dim3(64), 0, s, any_device_word, 3u); }
 
 void launch_raygen(hipStream_t s, const PathState &P, const BatchDev &B, const CameraDev &C, uint64_t *wave_stats) {
     hipLaunchKernelGGL(k_raygen, dim3(wave_grid(P)), dim3(kBlockThreads), 0, s, P, B, C, wave_stats);

@@ -82,6 +82,27 @@ def test_noalloc_on_a_scene_too_big_for_lds(gpu_ctx):
     assert np.array_equal(bits(acc_n), bits(ref[1].reshape(-1))) and st_n["inner_visits"] == ref[2]["inner_visits"]
 
 
+def test_noalloc_first_thing_on_a_fresh_context_takes_no_device_memory():
+    """The entry point as the first render call of a new context, before any other call could have grown buffers or the
+    queues' scratch memory on its behalf: a moving-sphere scene (its shade kernel reserves a private segment) and a scene too
+    big for LDS.  Free device memory (hipMemGetInfo, through torch) is read right before and right after each call."""
+    dev = torch.device("cuda", 0)
+    for kind, nx, ny, ns, half in ((rrt_amd.SCENE_BOOK2CHAP2, 160, 96, 6, 11), (rrt_amd.SCENE_RANDOM_SPHERES, 72, 40, 3, 60)):
+        osc = OracleScene.build(kind, nx, ny, seed=0, half=half)
+        ref = osc.render(nx, ny, ns, seed=2, threads=8)
+        n = nx * ny * 3
+        rgb = torch.zeros(n, dtype=torch.uint8, device=dev)
+        acc = torch.zeros(n, dtype=torch.float32, device=dev)
+        with rrt_amd.Context(0) as ctx:
+            _upload(ctx, osc)
+            torch.cuda.synchronize()
+            free_before = torch.cuda.mem_get_info()[0]
+            st = ctx.render_device_noalloc(rrt_amd.Context.params(nx, ny, ns, seed=2), rgb.data_ptr(), acc.data_ptr())
+            free_after = torch.cuda.mem_get_info()[0]
+            assert free_after >= free_before, f"{free_before - free_after} bytes of device memory taken during the call"
+            assert np.array_equal(bits(acc.cpu().numpy()), bits(ref[1].reshape(-1))) and st["rays"] == ref[2]["rays"]
+
+
 def test_noalloc_rejects_what_does_not_fit(gpu_ctx):
     osc = OracleScene.build(rrt_amd.SCENE_CHAP11, 8, 8)
     _upload(gpu_ctx, osc)
