@@ -950,7 +950,13 @@ static_assert(RRT_MAT_LAMBERTIAN == CL_LAMB && RRT_MAT_METAL == CL_METAL && RRT_
 
 // LDS words per wave: one 16-byte entry per list position
 constexpr uint32_t kShadeLdsWords = kWaveSlots * 4u;
-constexpr uint32_t kShadeTableThreads = 512;   // block size of the variant that keeps the per-sphere tables in LDS
+#ifndef RRT_SHADE_TABLE_THREADS
+#define RRT_SHADE_TABLE_THREADS 512
+#endif
+#ifndef RRT_SHADE_TABLE_WAVES
+#define RRT_SHADE_TABLE_WAVES 4
+#endif
+constexpr uint32_t kShadeTableThreads = RRT_SHADE_TABLE_THREADS;   // block size of the variant that keeps the per-sphere tables in LDS
 static_assert(kShadeTableSpheres <= 1024, "the narrow trail entries have 10 bits");  // kernels.h: the largest scene the table variant takes, 2 x 16 bytes per sphere
 
 // What step 3 reads of one path slot
@@ -1423,7 +1429,7 @@ DEV uint32_t shade_wave(const SceneDev &S, const PathState &P, const BatchDev &B
 }
 
 template <bool MOVING, bool COUNT, bool TABLES>
-__global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads, (TABLES || !MOVING) ? 4 : 3) void k_shade(SceneDev S, PathState P, BatchDev Bt, CameraDev C,
+__global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads, TABLES ? RRT_SHADE_TABLE_WAVES : (!MOVING ? 4 : 3)) void k_shade(SceneDev S, PathState P, BatchDev Bt, CameraDev C,
                                                                                       uint64_t *wave_stats) {
     constexpr uint32_t kThreads = TABLES ? kShadeTableThreads : kBlockThreads;
     extern __shared__ uint4 lds4[];  // per wave kShadeLdsWords words, then (TABLES) the sphere and material tables
