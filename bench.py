@@ -231,6 +231,7 @@ def main():
     def render_fn(p):
         p.count_work = int(flags["count"])
         p.reserved[0] = TIME_STRIDE if flags["timed"] else 0
+        p.path_slots = flags.get("slots", 0)
         st = ctx.render_device(p, 0 if want_accum else rgb8.data_ptr(), accum.data_ptr() if want_accum else 0)
         return rgb8, (accum if want_accum else None), st
 
@@ -284,8 +285,12 @@ def main():
     if not args.no_roofline:
         cst = step(count=True)  # every rank takes part (the pass ends in the same combine); rank 0 reports its own counters
         # one more step with the path pool in one part on one stream: extend launches that overlap nothing
+        # (with 4 Mi path slots: 1024 extend workgroups, two full generations on the chip's 512 places; the default pool of 3.5 Mi
+        # is sized for two parts on two streams and would leave the second generation a quarter empty here)
         os.environ["RRT_STREAMS"] = "1"
+        flags["slots"] = 1 << 22
         ist = step(timed=True)
+        flags["slots"] = 0
         del os.environ["RRT_STREAMS"]
         if rank == 0 and ext_ms > 0:
             flops = extend_flops(cst) * args.steps
@@ -309,7 +314,7 @@ def main():
                 "isolated": {"achieved": round(extend_flops(cst) / (ist["extend_ms"] * TIME_STRIDE * 1e-3) / 1e12, 3),
                              "frac": round(extend_flops(cst) / (ist["extend_ms"] * TIME_STRIDE * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 4),
                              "launches": ist["extend_launches"] * TIME_STRIDE, "avg_launch_ms": round(ist["extend_ms"] / max(1, ist["extend_launches"]), 4),
-                             "step_ms": round(ist["gpu_ms"], 2)},
+                             "step_ms": round(ist["gpu_ms"], 2), "path_slots": 1 << 22},
                 "whole_job": {"achieved": round(job_flops(cst) * args.steps / elapsed / 1e12, 3), "unit": "TFLOP/s",
                               "frac": round(job_flops(cst) * args.steps / elapsed / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 4),
                               "note": "all algorithmic FLOPs of a step (every kernel) over wall time, per GPU (rank 0's share)"},

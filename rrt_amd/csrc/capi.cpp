@@ -56,7 +56,7 @@ struct DevBuf {
     template <class T> T *as() const { return static_cast<T *>(p); }
 };
 
-constexpr uint32_t kDefaultSlots = 1u << 22;
+constexpr uint32_t kDefaultSlots = 14336u * kWaveSlots;  // 3.5 Mi: the headline render is 1-2 % faster than with 4 Mi, the other configurations within 1 % (profiles/r03_sweep_slots.txt)
 constexpr size_t kRadBudgetBytes = size_t(16) << 30;  // per-batch radiance planes; HBM is 288 GB (capped by what is free)
 constexpr uint32_t kMaxBatchPaths = 1u << 30;
 constexpr uint32_t kMaxParts = 4;       // parts of the path pool that run on streams of their own
@@ -500,7 +500,7 @@ int render_queued(rrt_ctx *c, const rrt_render_params &P, const RenderTarget &T,
             part[h].wave_end = (uint32_t)((uint64_t)n_waves * (h + 1) / n_parts);
             part_stream[h] = h == 0 ? s : c->side_stream[h - 1];
         }
-            uint32_t chunk = kChunk;
+            uint32_t chunk = kChunk, rounds_done = 0;
         // (not for the entry point that must allocate nothing: the finishing kernel spills a few registers, and the runtime
         // allocates the memory spills go to when such a kernel is first launched)
         const bool can_finish = !no_alloc && finish_fits(sd, ps) && !std::getenv("RRT_NO_FINISH");
@@ -523,6 +523,7 @@ int render_queued(rrt_ctx *c, const rrt_render_params &P, const RenderTarget &T,
             // Once every path of the batch has been dealt (at once, if the batch is no larger than the pool), what is left
             // thins out over up to max_depth more rounds: where the scene allows it, one launch runs them all.
             bool dealt = can_finish && (uint64_t)bd.n_paths <= slots;
+            uint64_t claimed_before = std::min<uint64_t>(slots, bd.n_paths);  // raygen deals the first paths
             for (;;) {
                 HIP_TRY(hipMemsetAsync(flags, 0, kFlagWords * 4, s));
                 if (dealt) {
@@ -549,6 +550,7 @@ int render_queued(rrt_ctx *c, const rrt_render_params &P, const RenderTarget &T,
                     }
                 }
                 st.iterations += chunk;
+                rounds_done = chunk;
                 chunk = std::min(kMaxChunk, chunk * 2u);
                 for (uint32_t h = 1; h < n_parts; h++) { HIP_TRY(hipEventRecord(c->ev_join[h - 1], part_stream[h])); HIP_TRY(hipStreamWaitEvent(s, c->ev_join[h - 1], 0)); }
                 }
@@ -561,10 +563,21 @@ int render_queued(rrt_ctx *c, const rrt_render_params &P, const RenderTarget &T,
                 for (uint32_t k = 0; k < kFlagWords; k += 32) any |= c->h_flags[k];
                 if (can_finish && !dealt) {  // dealt: the next claim of every cursor shard lies past the batch (kernels.hip: path_of_claim)
                     dealt = true;
-                    for (uint32_t k = 0; k < bd.n_shards && dealt; k++) {
+                    uint64_t claimed = 0;
+                    for (uint32_t k = 0; k < bd.n_shards; k++) {
                         const uint64_t n = c->h_flags[kFlagWords + k * kCursorStride];
+                        claimed += n;
                         if (((n >> 6) * bd.n_shards + k) * 64ull + (n & 63u) < (uint64_t)bd.n_paths) dealt = false;
                     }
+                    // The rounds after the last path is dealt belong to the finishing launch: the next chunk is no longer than
+                    // the rounds the batch's remaining paths last at the rate the last chunk took them.
+                    claimed = std::min<uint64_t>(claimed, bd.n_paths);
+                    if (!dealt && rounds_done != 0 && claimed > claimed_before) {
+                        const double per_round = (double)(claimed - claimed_before) / rounds_done;
+                        const double left = (double)(bd.n_paths - claimed) / per_round;
+                        if (left < (double)chunk) chunk = std::max(1u, (uint32_t)std::ceil(left));
+                    }
+                    claimed_before = claimed;
                 }
                 if (T.progress) {
                     // Paths handed out so far, less those that may still be in flight, are finished; a pixel counts as
