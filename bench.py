@@ -138,7 +138,7 @@ def other_configs(ctx, rrt_amd, torch, dev):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         # the whole BVH is walked in an LDS copy when its compact image fits 16-bit offsets: node reads are then not memory traffic
-        in_lds = (scene.n_spheres - 1) * 68 + 4 + scene.n_spheres * 52 <= 0xFFF0
+        in_lds = (scene.n_spheres - 1) * 80 + 4 + scene.n_spheres * 52 <= 0xFFF0
         hits = cst["hits_lambertian"] + cst["hits_metal"] + cst["hits_dielectric"]
         per_ray = ((16 * hits + 120 * cst["rays"]) if in_lds else job_bytes(cst, 0)) / cst["rays"]
         gbs = per_ray * st["rays"] / dt / 1e9

@@ -218,7 +218,7 @@ DEV V3 origin(const RayCtx &r) { return mk(r.ox.x, r.oy.x, r.oz.x); }
 DEV void ray_finish(RayCtx &r, float tmin, float tmax, const SceneDev &S, bool uniform_times) {
     const uint32_t nx = r.ox.y < 0.0f ? 1u : 0u, ny = r.oy.y < 0.0f ? 1u : 0u, nz = r.oz.y < 0.0f ? 1u : 0u;  // acceleration.rs:230-231
     r.oct = nx | (ny << 1) | (nz << 2);
-    r.cx = nx << 2; r.cy = 12u + (ny << 2); r.cz = 24u + (nz << 2);
+    r.cx = nx << 3; r.cy = 16u + (ny << 3); r.cz = 32u + (nz << 3);
     r.link = kSmallLinkOffset + (r.oct << 2);
     r.leaf_link = S.small_leaf_links + (r.oct << 1);
     r.f_ray = uniform_times ? (r.time - S.u_time0) / S.u_dt : 0.0f;  // center_at's factor when every moving sphere shares its shutter interval
@@ -342,11 +342,12 @@ struct LdsStore {
     typedef const __attribute__((address_space(3))) uint16_t *LdsHalfPtr;
     DEV static LdsWordPtr words(uint32_t lds_addr) { return reinterpret_cast<LdsWordPtr>(static_cast<uintptr_t>(lds_addr)); }
     DEV static LdsFloatPtr floats(uint32_t lds_addr) { return reinterpret_cast<LdsFloatPtr>(static_cast<uintptr_t>(lds_addr)); }
-    DEV static f32x2 pair_at(uint32_t lds_addr) { const LdsFloatPtr f = floats(lds_addr); return f32x2{f[0], f[1]}; }
+    typedef const __attribute__((address_space(3))) f32x2 *LdsPairPtr;
+    DEV static f32x2 pair_at(uint32_t lds_addr) { return *reinterpret_cast<LdsPairPtr>(static_cast<uintptr_t>(lds_addr)); }  // 8-byte aligned: ds_read_b64
     DEV void prepare(RayCtx &) const {}
-    // The box is stored per axis as (min, max, min): the pair that starts one word in is (max, min), so a ray that is
-    // negative along the axis reads (near, far) directly, with an address instead of a select.  `links` comes back as
-    // near child | exit link << 16 for the ray's octant.
+    // The box is stored per axis as (min, max, max, min): the second pair is (max, min), so a ray that is negative along
+    // the axis reads (near, far) directly, with an address instead of a select.  `links` comes back as near child | exit
+    // link << 16 for the ray's octant.
     DEV void inner(uint32_t cur, const RayCtx &r, f32x2 &bx, f32x2 &by, f32x2 &bz, uint32_t &links) const {
         bx = pair_at(cur + r.cx); by = pair_at(cur + r.cy); bz = pair_at(cur + r.cz);
         links = *words(cur + r.link);

@@ -213,7 +213,7 @@ int build_scene_layout(const rrt_sphere_soa *sp, const rrt_material_soa *mt, con
             const uint32_t *w = &out.nodes[static_cast<size_t>(i) * kNodeWords];
             uint32_t *s = &out.small_nodes[off[i] / 4u];
             if (out.node_kind[i] == 1) {
-                for (int k = 0; k < 3; k++) { s[3 * k] = w[2 * k]; s[3 * k + 1] = w[2 * k + 1]; s[3 * k + 2] = w[2 * k]; }
+                for (int k = 0; k < 3; k++) { s[4 * k] = w[2 * k]; s[4 * k + 1] = w[2 * k + 1]; s[4 * k + 2] = w[2 * k + 1]; s[4 * k + 3] = w[2 * k]; }
                 const uint32_t axis = (w[6] >> RRT_NODE_AXIS_SHIFT) & 3u;
                 const uint32_t left = ref16(w[7]), right = ref16(w[6] & (kRefLeafBit | kRefIndexMask));
                 for (uint32_t o = 0; o < 8; o++) {

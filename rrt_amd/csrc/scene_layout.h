@@ -26,13 +26,13 @@ constexpr uint32_t kLeafPrimMask = 0x3FFFFFFFu; // leaf word 4: sphere index | m
 constexpr uint32_t kLeafKindShift = 30;
 
 // Compact layout for scenes small enough to live in a workgroup's LDS.  A 16-bit reference is the node's byte offset
-// in the image (= its LDS address: the image starts at LDS address 0).  Inner nodes (68 bytes) come first, then one
+// in the image (= its LDS address: the image starts at LDS address 0).  Inner nodes (80 bytes) come first, then one
 // unused word whose offset is the reference that means "nothing left to visit", then the leaves (36 bytes, or 52 in a
 // scene with moving spheres); so `ref < end` is an inner node and `ref > end` a leaf.
-constexpr uint32_t kSmallInnerBytes = 68;
+constexpr uint32_t kSmallInnerBytes = 80;
 constexpr uint32_t kSmallLeafBytes = 36;        // centre, radius^2, sphere word, 8 exit links of 16 bits
 constexpr uint32_t kSmallLeafBytesMoving = 52;  // + moving flag and centre1 - centre0
-constexpr uint32_t kSmallLinkOffset = 36;       // inner: byte offset of the 8 (near child | exit << 16) words
+constexpr uint32_t kSmallLinkOffset = 48;       // inner: byte offset of the 8 (near child | exit << 16) words
 constexpr uint32_t kSmallLdsBudget = 0xFFF0u;   // every offset fits 16 bits
 
 // Per-sphere info word: material index | kind << 28 | moving << 31
@@ -66,10 +66,11 @@ struct SceneLayout {
     uint32_t max_leaf_depth = 0;
 
     // Compact image (empty when the scene does not qualify), as words.
-    // Inner: [0..8] per axis (min, max, min), so that the two words starting at 3 * axis + s are (near, far) for a ray
-    //        whose direction is negative (s = 1) or not (s = 0) along that axis; [9..16] for each of the 8 sign octants of
-    //        the ray direction: reference of the child the reference visits first (acceleration.rs:253-267) in the low
-    //        half, exit link in the high half.
+    // Inner: [0..11] per axis (min, max, max, min), so that the two words starting at 4 * axis + 2 * s are (near, far) for a
+    //        ray whose direction is negative (s = 1) or not (s = 0) along that axis, and either pair is 8-byte aligned: one
+    //        ds_read_b64 (2 LDS cycles per wave) instead of the ds_read2_b32 (4 cycles) a pair at a 4-byte boundary takes;
+    //        [12..19] for each of the 8 sign octants of the ray direction: reference of the child the reference visits
+    //        first (acceleration.rs:253-267) in the low half, exit link in the high half.
     // Leaf:  [0..2] centre at time0, [3] radius^2, [4] sphere index | kind << 30, then (scenes with moving spheres)
     //        [5] bit 0 = moving, [6..8] centre1 - centre0, then four words of eight 16-bit exit links.
     std::vector<uint32_t> small_nodes;
