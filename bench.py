@@ -177,6 +177,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp", type=int, default=0, help="samples per pixel of the whole job (default: 500 at N = 1, 1024 at N > 1)")
     ap.add_argument("--shard", choices=("tile", "sample"), default="tile", help="how N > 1 ranks share the image")
+    ap.add_argument("--slots", type=int, default=0, help="path slots in flight (default: the library's, 3.5 Mi)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
@@ -224,7 +225,7 @@ def main():
     accum = torch.zeros(ny * nx * 3 if want_accum else 3, dtype=torch.float32, device=dev)
     rgb8 = torch.zeros(ny * nx * 3, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
-    flags = {"count": False, "timed": False}
+    flags = {"count": False, "timed": False, "slots": args.slots}
 
     TIME_STRIDE = 4  # HIP events around every 4th extend launch: an even sample, a quarter of the event traffic
 
@@ -290,7 +291,7 @@ def main():
         os.environ["RRT_STREAMS"] = "1"
         flags["slots"] = 1 << 22
         ist = step(timed=True)
-        flags["slots"] = 0
+        flags["slots"] = args.slots
         del os.environ["RRT_STREAMS"]
         if rank == 0 and ext_ms > 0:
             flops = extend_flops(cst) * args.steps

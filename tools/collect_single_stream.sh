@@ -5,7 +5,7 @@ out=$GRAFT_REPO_ROOT/gpurun_out/prof_${tag}_1s
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export RRT_STREAMS=1
-args="bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-other-configs"
+args="bench.py --steps 1 --warmup 0 --slots 4194304 --no-cpu-baseline --no-roofline --no-other-configs"  # 4 Mi slots: two full generations of extend workgroups on one stream
 timeout -s KILL 200 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS SQ_INSTS_SALU --output-format csv -d $out/pmc_s -- python $args > /dev/null 2> $out/pmc_s.log || exit 1
 python tools/pmc_summary.py $out/pmc_s > $out/pmc_sq.txt
 timeout -s KILL 200 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $out/pmc_t -- python $args > /dev/null 2> $out/pmc_t.log || exit 1

@@ -28,6 +28,23 @@ for name, key in (("extend", "k_extend"), ("shade", "k_shade")):
                          "valu_busy": round(4.0 * sq[ks]["SQ_ACTIVE_INST_VALU"] / 1024.0 / (sq[ks]["GRBM_GUI_ACTIVE"] / 8.0), 3),
                          "valu_insts_per_ray": round(sq[ks]["SQ_INSTS_VALU"] / rays, 1),
                          "avg_l2_read_latency_cycles": round(sq[ks]["TCP_TCC_READ_REQ_LATENCY_sum"] / sq[ks]["TCP_TCC_READ_REQ_sum"])}
+        if "SQ_THREAD_CYCLES_VALU" in sq[ks]:
+            out["extend"]["lane_util"] = round(sq[ks]["SQ_THREAD_CYCLES_VALU"] / (64.0 * sq[ks]["SQ_INSTS_VALU"]), 3)
+        passes = os.path.join(ROOT, "profiles", f"{tag}_cfg5_extend_passes.txt")
+        if os.path.exists(passes):  # tools/extend_passes.py 3 1920 1080 8 500 (counting build)
+            t = open(passes).read()
+            g = lambda pat: [float(x) for x in re.search(pat, t).groups()]
+            d, dl = g(r"descent passes per 64 rays ([0-9.]+) lanes/pass ([0-9.]+)")
+            sp, sl = g(r"sphere passes per 64 rays ([0-9.]+) lanes/pass ([0-9.]+)")
+            h, hl = g(r"hand-outs per 64 rays ([0-9.]+) lanes/hand-out ([0-9.]+)")
+            out["extend"]["passes_per_64_rays"] = {"descent": d, "lanes_per_descent_pass": dl, "sphere": sp, "lanes_per_sphere_pass": sl, "hand_outs": h, "lanes_per_hand_out": hl,
+                                                   "note": "a descent pass of the two-children walk deals with both children of each lane's node; leaf children are tested inside it"}
+    else:
+        ks = next(k for k in sq if k.startswith(key))
+        out["shade"] = {"kernel": kf, "valu_busy": round(4.0 * sq[ks]["SQ_ACTIVE_INST_VALU"] / 1024.0 / (sq[ks]["GRBM_GUI_ACTIVE"] / 8.0), 3),
+                        "valu_insts_per_ray": round(sq[ks]["SQ_INSTS_VALU"] / rays, 1)}
+        if "SQ_THREAD_CYCLES_VALU" in sq[ks]:
+            out["shade"]["lane_util"] = round(sq[ks]["SQ_THREAD_CYCLES_VALU"] / (64.0 * sq[ks]["SQ_INSTS_VALU"]), 3)
 out["bytes_per_ray"]["total"] = round(total, 1)
 json.dump(out, open(os.path.join(ROOT, "profiles", "cfg5_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

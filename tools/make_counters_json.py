@@ -9,8 +9,9 @@ Definitions (MI355X guide units: SQ_ACTIVE_INST_* and SQ_WAVE_CYCLES count quad-
                      issues in 2.3 cycles (v_fma/v_add/v_mul/v_sub_f32, v_add_u32, v_and/or/xor, v_mov) still counts one quad-cycle.
   lane_util          SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU)
   lds_conflict_frac  SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
-  bytes_per_ray      (2 x FETCH_SIZE + WRITE_SIZE) x 1024 / rays, per kernel, default (two-stream) run; FETCH_SIZE doubled per
-                     the gfx950 rule for 16-byte-per-lane streaming loads
+  bytes_per_ray      (2 x FETCH_SIZE + WRITE_SIZE) x 1024 / rays, per kernel, default (two-stream) run; FETCH_SIZE reports half the
+                     bytes of a coalesced stream at every width these kernels use (4, 8, 12, 16 bytes per lane, and 16-byte loads
+                     straight into LDS: factor 2.000 each, WRITE_SIZE 1.000; tools/micro/fetch_size.hip, profiles/r03_fetch_size.txt)
 """
 import json
 import os
@@ -70,7 +71,7 @@ def main():
             with open(P("extend_traffic.json"), "w") as fo:
                 json.dump({"kernel": k1, "source": f"profiles/{tag}_pmc_fetch.txt + profiles/{tag}_pmc_write.txt", "fetch_size_kb_per_launch": round(f["FETCH_SIZE"] / f["dispatches"], 1),
                            "write_size_kb_per_launch": round(w["WRITE_SIZE"] / w["dispatches"], 1), "fetch_correction": 2.0, "bytes_per_launch": round(per),
-                           "note": "FETCH_SIZE doubled per the gfx950 rule for 16-byte-per-lane streaming loads; a launch is one half of the 4 Mi-slot path pool"}, fo)
+                           "note": "FETCH_SIZE doubled (calibrated per access width: profiles/r03_fetch_size.txt); a launch is one half of the path pool (3.5 Mi slots by default)"}, fo)
     bpr["total"] = round(bpr["extend"] + bpr["shade"], 1)
     res["bytes_per_ray"] = bpr
     # the whole step as it runs by default: VALU quad-cycles of both kernels over the step's wall time
