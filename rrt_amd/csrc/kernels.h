@@ -49,13 +49,20 @@ struct SceneDev {
 };
 
 // All per-path state lives in planes indexed by slot.  A wave owns slots [wave*kWaveSlots, +kWaveSlots)
-// and the matching stretch of `queue`, which lists its live slots; `qcount[wave]` is the list length.
+// and the matching stretch of `queue`, which lists its live slots; the low half of `qcount[wave]` is the list length, the
+// high half the number of entries at the front of the list whose paths have just started (their rays are camera rays).
 // PathState::layout bits.  kLayoutTimed: the origin plane carries the ray's time in a fourth word (scenes with moving
 // spheres; elsewhere nothing reads the time and the plane is packed, 12 bytes per slot).  kLayoutNarrow: depth, trail
 // length and the four newest trail entries share one 8-byte record per slot in the `recent` plane (8 bits each for the
 // counts, 10 bits per entry: scenes of at most 1024 spheres rendered with a depth limit of at most 255); otherwise a
 // 4-byte `depth` plane and 16 bytes per slot in `recent`.
-constexpr uint32_t kLayoutTimed = 1u, kLayoutNarrow = 2u;
+// kLayoutFreshApart: the shade kernel writes every list with the freshly started paths first (a full list too, which is
+// otherwise left as it is), and an extend workgroup whose lists are all full takes its rays in the order "paths under way
+// of all its lists, then the fresh ones".  Camera rays of neighbouring pixels walk the tree alike and end together; rays
+// that have bounced do not, whatever they are sorted by.  With the camera rays last, the end of a workgroup's pool, where
+// its waves run out of rays to take one lane after the other, is short.
+constexpr uint32_t kLayoutTimed = 1u, kLayoutNarrow = 2u, kLayoutFreshApart = 4u;
+constexpr uint32_t kListCountMask = 0xFFFFu, kListFreshShift = 16;
 constexpr uint32_t kNarrowMaxDepth = 255;
 constexpr uint32_t kShadeTableSpheres = 512;  // scenes up to this size: the shade kernel keeps the sphere tables in LDS and the path state narrow
 

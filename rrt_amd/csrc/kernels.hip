@@ -622,11 +622,13 @@ DEV uint64_t wave_sum_u64(uint64_t v) {
 // until at least `retire_min` of them can be retired and restarted in one go (or nothing else is left).
 template <class Store, bool MOVING, bool COUNT>
 DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uint32_t wave, uint32_t lane, uint32_t retire_min,
-                     uint32_t leaf_min, uint64_t *wave_stats, uint32_t own_count, uint32_t *pool_head, uint32_t pool_base, uint32_t pool_total) {
+                     uint32_t leaf_min, uint64_t *wave_stats, uint32_t own_count, uint32_t *pool_head, uint32_t pool_base, uint32_t pool_total,
+                     bool pool_listed = false) {
     // Where the wave's rays come from.  Usually (pool_head != null) from a pool shared by the waves of the workgroup:
     // when every live-slot list of the workgroup is full, the lists are one run of consecutive slots, and idle lanes of
     // any wave take the next ones off a counter in LDS.  All waves then stay busy until the run is used up, instead of
-    // each wave trailing off at the end of its own 256 rays.  Otherwise from the wave's own list.
+    // each wave trailing off at the end of its own 256 rays.  Otherwise from the wave's own list.  `pool_listed`: the pool's
+    // stretch of the list plane says in which order the pool's slots are taken (order_pool has written it).
     const bool pooled = pool_head != nullptr;
     const uint32_t base = pooled ? pool_base : wave * kWaveSlots;
     const uint32_t count = pooled ? pool_total : own_count;
@@ -679,6 +681,7 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
                 n_slot = col == 0u ? s0 : (col == 1u ? s1 : (col == 2u ? s2 : s3));
             }
             const bool take = idle && pos < count;
+            if (pool_listed && take) n_slot = P.queue[base + pos];
             if (idle && has) {
                 P.hit[slot] = make_uint2(f2u(r.tmax), r.best == kPrimNone ? kPrimNone : st.prim_of(r.best));
                 has = false;
@@ -745,13 +748,48 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
     if (lane == 0) stt[ST_RAYS] += n_taken;
 }
 
+// (kLayoutFreshApart) The order in which a workgroup's pool of full lists is taken: the slots whose paths are under way, list
+// by list, then the freshly started ones, list by list.  Every list arrives with its fresh slots first (`own_word`: the
+// list's word of P.qcount); the order is written over the workgroup's stretch of the list plane, which nobody reads as lists
+// while the lists are full (the shade kernel takes a full list to be every slot in order, and rewrites it).  `fresh`: one
+// LDS word per wave of the workgroup.  Called by every wave of the workgroup; the last barrier makes the order visible (one
+// workgroup runs on one CU: its waves read through the same cache).
+DEV void order_pool(const PathState &P, uint32_t *fresh, uint32_t wave0, uint32_t n_lists, uint32_t own_word) {
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const bool mine = w < n_lists;
+    const uint32_t n_fresh = own_word >> kListFreshShift;
+    if (lane == 0) fresh[w] = mine ? n_fresh : 0u;
+    uint32_t q[4] = {0u, 0u, 0u, 0u};
+    if (mine) {
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; k++) q[k] = P.queue[(wave0 + w) * kWaveSlots + lane + 64u * k];
+    }
+    __syncthreads();  // the counts are there
+    uint32_t fresh_before = 0, fresh_total = 0;
+    for (uint32_t b = 0; b < n_lists; b++) {
+        const uint32_t v = rfl(fresh[b]);
+        fresh_total += v;
+        if (b < w) fresh_before += v;
+    }
+    __syncthreads();  // every list has been read
+    if (mine) {
+        const uint32_t at_fresh = n_lists * kWaveSlots - fresh_total + fresh_before, at_rest = w * kWaveSlots - fresh_before;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; k++) {
+            const uint32_t e = lane + 64u * k;
+            P.queue[wave0 * kWaveSlots + (e < n_fresh ? at_fresh + e : at_rest + (e - n_fresh))] = q[k];
+        }
+    }
+    __syncthreads();
+}
+
 template <bool MOVING, bool COUNT>
 __global__ __launch_bounds__(kBlockThreads) void k_extend(SceneDev S, PathState P, uint32_t retire_min, uint32_t leaf_min, uint64_t *wave_stats) {
     __shared__ uint32_t pool[2];  // next position of the workgroup's ray pool; sum of the workgroup's list lengths
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave0 = P.wave_begin + blockIdx.x * (kBlockThreads / 64u);
     const uint32_t wave = wave0 + (threadIdx.x >> 6);
-    const uint32_t own_count = wave < P.wave_end ? rfl(P.qcount[wave]) : 0u;
+    const uint32_t own_count = wave < P.wave_end ? rfl(P.qcount[wave]) & kListCountMask : 0u;
     if (threadIdx.x < 2) pool[threadIdx.x] = 0u;
     __syncthreads();
     if (lane == 0 && own_count) atomicAdd(&pool[1], own_count);
@@ -775,26 +813,30 @@ DEV void extend_lds_block(const SceneDev &S, const PathState &P, uint32_t retire
     const uint32_t n_vec = (S.small_bytes + 15u) / 16u;  // 16-byte pieces; the host pads the image to a whole number of them
     // next position of the workgroup's ray pool; sum of the workgroup's list lengths.  Behind the nodes, so that the nodes
     // start at LDS address 0 and a node reference needs no base added
+    // (then a word per wave for order_pool)
     uint32_t *pool = reinterpret_cast<uint32_t *>(lds4 + n_vec);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave0 = P.wave_begin + blockIdx.x * (kLdsBlockThreads / 64u);
     const uint32_t wave = wave0 + (threadIdx.x >> 6);
-    const uint32_t own_count = wave < P.wave_end ? rfl(P.qcount[wave]) : 0u;
+    const uint32_t own_word = wave < P.wave_end ? rfl(P.qcount[wave]) : 0u;
+    const uint32_t own_count = own_word & kListCountMask;
     if (threadIdx.x < 2) pool[threadIdx.x] = 0u;
     for (uint32_t i = threadIdx.x; i < n_vec; i += kLdsBlockThreads) lds4[i] = S.small_nodes[i];
     __syncthreads();
     if (lane == 0 && own_count) atomicAdd(&pool[1], own_count);
     __syncthreads();
-    if (wave >= P.wave_end) return;
     const uint32_t n_lists = min(kLdsBlockThreads / 64u, P.wave_end - wave0);
     const uint32_t total = rfl(pool[1]);  // the same for every lane: say so, and the list bookkeeping stays in scalar registers
     const bool pooled = total == n_lists * kWaveSlots;
+    const bool listed = pooled && (P.layout & kLayoutFreshApart) != 0u;  // the same for every wave of the workgroup
+    if (listed) order_pool(P, pool + 4, wave0, n_lists, own_word);
+    if (wave >= P.wave_end) return;
     const LdsStore<MOVING> st(S.small_root, S.small_end);  // the image starts at LDS address 0: a reference is an LDS address
 #ifdef RRT_WAVE_TIMING
     const uint64_t wt1 = wall_clock64();
 #endif
     extend_wave<LdsStore<MOVING>, MOVING, COUNT>(st, S, P, wave, lane, retire_min, leaf_min, wave_stats, own_count, pooled ? &pool[0] : nullptr,
-                                                 wave0 * kWaveSlots, total);
+                                                 wave0 * kWaveSlots, total, listed);
 #ifdef RRT_WAVE_TIMING
     {   // time from the end of this wave's work to the end of the workgroup's: the wave's slot stays taken that long
         const uint64_t wt2 = wall_clock64();
@@ -828,16 +870,16 @@ __global__ __launch_bounds__(kLdsBlockThreads, 8) void k_extend_top(SceneDev S, 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave0 = P.wave_begin + blockIdx.x * (kLdsBlockThreads / 64u);
     const uint32_t wave = wave0 + (threadIdx.x >> 6);
-    const uint32_t own_count = wave < P.wave_end ? rfl(P.qcount[wave]) : 0u;
+    const uint32_t own_count = wave < P.wave_end ? rfl(P.qcount[wave]) & kListCountMask : 0u;
     if (threadIdx.x < 2) pool[threadIdx.x] = 0u;
     for (uint32_t i = threadIdx.x; i < S.n_top * 4u; i += kLdsBlockThreads) lds4[i] = S.top_nodes[i];
     __syncthreads();
     if (lane == 0 && own_count) atomicAdd(&pool[1], own_count);
     __syncthreads();
-    if (wave >= P.wave_end) return;
     const uint32_t n_lists = min(kLdsBlockThreads / 64u, P.wave_end - wave0);
     const uint32_t total = rfl(pool[1]);  // the same for every lane: say so, and the list bookkeeping stays in scalar registers
     const bool pooled = total == n_lists * kWaveSlots;
+    if (wave >= P.wave_end) return;
     const HbmStore<MOVING, LdsNodePtr> st(S, (LdsNodePtr)lds4);
     extend_wave<HbmStore<MOVING, LdsNodePtr>, MOVING, COUNT>(st, S, P, wave, lane, retire_min, leaf_min, wave_stats, own_count, pooled ? &pool[0] : nullptr,
                                                  wave0 * kWaveSlots, total);
@@ -854,7 +896,7 @@ __global__ __launch_bounds__(kLdsBlockThreads, 8) void k_extend_wide(SceneDev S,
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave0 = P.wave_begin + blockIdx.x * (kLdsBlockThreads / 64u);
     const uint32_t wave = wave0 + (threadIdx.x >> 6);
-    const uint32_t own_count = wave < P.wave_end ? rfl(P.qcount[wave]) : 0u;
+    const uint32_t own_count = wave < P.wave_end ? rfl(P.qcount[wave]) & kListCountMask : 0u;
     if (threadIdx.x < 2) pool[threadIdx.x] = 0u;
     const uint32_t n_top_lds = min(S.n_top, kWideTopLds);
     uint4 *top_copy = lds4 + kWideLdsEntries * kLdsBlockThreads / 2u;  // behind the stacks (8 bytes per entry)
@@ -862,10 +904,10 @@ __global__ __launch_bounds__(kLdsBlockThreads, 8) void k_extend_wide(SceneDev S,
     __syncthreads();
     if (lane == 0 && own_count) atomicAdd(&pool[1], own_count);
     __syncthreads();
-    if (wave >= P.wave_end) return;
     const uint32_t n_lists = min(kLdsBlockThreads / 64u, P.wave_end - wave0);
     const uint32_t total = rfl(pool[1]);
     const bool pooled = total == n_lists * kWaveSlots;
+    if (wave >= P.wave_end) return;
     const WideStore<MOVING, COUNT> st(S, (LdsNodePtr)top_copy, n_top_lds, (LdsStackPtr)lds4 + threadIdx.x);
     extend_wave<WideStore<MOVING, COUNT>, MOVING, COUNT>(st, S, P, wave, lane, retire_min, leaf_min, wave_stats, own_count, pooled ? &pool[0] : nullptr,
                                                         wave0 * kWaveSlots, total);
@@ -917,7 +959,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_raygen(PathState P, BatchDev 
         out_count += (uint32_t)__popcll(am);
     }
     if (lane == 0) {
-        P.qcount[wave] = out_count;
+        P.qcount[wave] = out_count | (out_count << kListFreshShift);  // every path of the list has just started
         if (out_count && Bt.alive_flag) Bt.alive_flag[(wave & 31u) * 32u] = 1u;  // 32 lines share the traffic
         wave_stats[(size_t)wave * kWaveStatWords + ST_PATHS] += out_count;
     }
@@ -1346,7 +1388,7 @@ DEV uint32_t shade_wave(const SceneDev &S, const PathState &P, const BatchDev &B
             if (pos < count) shade_slot<MOVING, Tables>(S, T, P, Bt, cls, slot, buf[t & 1u], l_ent[pos], np, alive, absorbed, started, &l_ent[pos], older);
             older_levels |= older << (8u * t);
             absorbed_bits |= absorbed ? (1u << t) : 0u;
-            alive_bits |= alive ? (1u << t) : 0u;
+            alive_bits |= (alive ? (1u << t) : 0u) | (started ? (16u << t) : 0u);  // bits 4..7: the slot's path has just started
             n_started += (uint32_t)__popcll(__ballot(started));
         }
     }
@@ -1395,26 +1437,34 @@ DEV uint32_t shade_wave(const SceneDev &S, const PathState &P, const BatchDev &B
 #ifdef RRT_SHADE_TIMING
     const uint64_t tk4 = __builtin_readcyclecounter();
 #endif
-    // ---- 5. the live-slot list, still in slot order (ballot + prefix popcount) ----
-    uint32_t out_count = 0;
-    uint64_t am[4];
+    // ---- 5. the live-slot list, in slot order (ballot + prefix popcount); kLayoutFreshApart: the slots whose path has just
+    // started first, then the others, both in slot order ----
+    const bool fresh_apart = (P.layout & kLayoutFreshApart) != 0u;
+    uint32_t out_count = 0, n_fresh = 0;
+    uint64_t am[4], fm[4];  // per column: live slots listed behind the fresh ones / fresh ones
 #pragma unroll
     for (uint32_t t = 0; t < 4u; t++) {
-        const bool alive = ((alive_bits >> t) & 1u) || (((absorbed_bits >> t) & 1u) && rank[t] < n_refilled);
-        am[t] = __ballot(alive);
-        out_count += (uint32_t)__popcll(am[t]);
+        const bool refilled = ((absorbed_bits >> t) & 1u) && rank[t] < n_refilled;
+        const bool alive = ((alive_bits >> t) & 1u) || refilled;
+        const bool fresh = fresh_apart && alive && (((alive_bits >> (4u + t)) & 1u) || refilled);
+        fm[t] = __ballot(fresh);
+        am[t] = __ballot(alive && !fresh);
+        n_fresh += (uint32_t)__popcll(fm[t]);
+        out_count += (uint32_t)__popcll(fm[t]) + (uint32_t)__popcll(am[t]);
     }
     // a full list is every slot of the wave in order; if it was full and stays full, what is in memory is already right
-    if (!(count == kWaveSlots && out_count == kWaveSlots)) {
-        uint32_t at = 0;
+    if (fresh_apart || !(count == kWaveSlots && out_count == kWaveSlots)) {
+        uint32_t at_f = 0, at = n_fresh;
 #pragma unroll
         for (uint32_t t = 0; t < 4u; t++) {
-            if ((am[t] >> lane) & 1ull) P.queue[base + at + prefix_count(am[t])] = sq[t];
+            const bool f = (fm[t] >> lane) & 1ull;
+            if (f || ((am[t] >> lane) & 1ull)) P.queue[base + (f ? at_f + prefix_count(fm[t]) : at + prefix_count(am[t]))] = sq[t];
+            at_f += (uint32_t)__popcll(fm[t]);
             at += (uint32_t)__popcll(am[t]);
         }
     }
     if (lane == 0) {
-        P.qcount[wave] = out_count;
+        P.qcount[wave] = out_count | (n_fresh << kListFreshShift);
         if (out_count && Bt.alive_flag) Bt.alive_flag[(wave & 31u) * 32u] = 1u;  // 32 lines share the traffic
         uint64_t *st = wave_stats + (size_t)wave * kWaveStatWords;
         st[ST_PATHS] += n_started + n_refilled;
@@ -1455,7 +1505,7 @@ __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads, TABLES
         T.att = S.prim_att;
     }
     if (wave >= P.wave_end) return;
-    const uint32_t count = rfl(count_word);
+    const uint32_t count = rfl(count_word) & kListCountMask;
     if (count == 0) return;
     shade_wave<MOVING, COUNT, Tables>(S, P, Bt, C, T, lds4 + (threadIdx.x >> 6) * (kShadeLdsWords / 4u), wave, lane, count, wave_stats);
 #ifdef RRT_WAVE_TIMING
@@ -1481,7 +1531,7 @@ __global__ __launch_bounds__(kFinishThreads, 4) void k_finish(SceneDev S, PathSt
     const uint4 *src_s = reinterpret_cast<const uint4 *>(S.sph), *src_a = reinterpret_cast<const uint4 *>(S.prim_att);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = P.wave_begin + blockIdx.x * (kFinishThreads / 64u) + (threadIdx.x >> 6);
-    uint32_t count = P.qcount[min(wave, P.wave_end - 1u)];
+    uint32_t count = P.qcount[min(wave, P.wave_end - 1u)] & kListCountMask;
     {   // nothing left in this workgroup's lists: leave before the copies (no static LDS: the image must start at address 0)
         uint32_t *any = reinterpret_cast<uint32_t *>(ents);
         if (threadIdx.x == 0) *any = 0u;
@@ -1627,7 +1677,7 @@ void launch_extend(hipStream_t s, const SceneDev &S, const PathState &P, bool mo
     if (S.small_nodes) {  // scene fits in LDS
         const uint32_t waves_per_block = kLdsBlockThreads / 64u;
         const dim3 g((P.wave_end - P.wave_begin + waves_per_block - 1u) / waves_per_block), b(kLdsBlockThreads);
-        const size_t lds = (((size_t)S.small_bytes + 15u) & ~(size_t)15u) + 16u;  // the image, then the pool counters
+        const size_t lds = (((size_t)S.small_bytes + 15u) & ~(size_t)15u) + 16u + 4u * waves_per_block;  // the image, the pool counters, a word per wave
         if (moving) {
             if (count) hipLaunchKernelGGL((k_count_extend_lds<true>), g, b, lds, s, S, P, retire_min, leaf_min, wave_stats);
             else hipLaunchKernelGGL((k_extend_lds<true, false>), g, b, lds, s, S, P, retire_min, leaf_min, wave_stats);

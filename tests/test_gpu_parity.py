@@ -190,6 +190,18 @@ def test_pool_parts_and_streams_do_not_change_the_image(gpu_ctx, monkeypatch):
         monkeypatch.setenv("RRT_STREAMS", parts)
         gpu = gpu_ctx.render(rrt_amd.Context.params(nx, ny, ns, seed=4, path_slots=256 * 1024))
         assert_same_image(gpu, ref)
+    # the order in which an extend workgroup takes the rays of its pool (camera rays last, or slot order): same bits, same
+    # work, and a scene with moving spheres as well
+    for kind, seed in (("chap12", 0), ("book2chap2", 3)):
+        osc = OracleScene.build(SCENES[kind], nx, ny, seed=seed)
+        upload_from_oracle(gpu_ctx, osc)
+        ref = osc.render(nx, ny, ns, seed=7, threads=8)
+        for apart in ("0", "1"):
+            monkeypatch.setenv("RRT_FRESH_APART", apart)
+            gpu = gpu_ctx.render(rrt_amd.Context.params(nx, ny, ns, seed=7, path_slots=256 * 1024, count_work=True))
+            assert_same_image(gpu, ref)
+            for k in ("rays", "inner_visits", "leaf_tests", "paths"):
+                assert gpu[2][k] == ref[2][k], (kind, apart, k)
 
 
 def test_finishing_launch_and_plain_rounds_agree(gpu_ctx, monkeypatch):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B timing of render-parameter variants, interleaved rounds in one process.
-   python tools/tune.py [--spp 500] [--rounds 3] name=key:val,key:val ...   (keys: path_slots, batch_samples, retire_min, force_hbm_bvh)"""
+   python tools/tune.py [--spp 500] [--rounds 3] name=key:val,key:val ...   (keys: path_slots, batch_samples, retire_min, force_hbm_bvh; env_NAME:value sets an environment variable for that variant)"""
 import argparse
 import os
 import statistics
@@ -35,6 +35,13 @@ def main():
     res = {k: [] for k in variants}
     for r in range(a.rounds + 1):
         for name, kw in variants.items():
+            kw = dict(kw)
+            for key in [k for k in kw if k.startswith("env_")]:  # env_NAME:value sets an environment variable the library reads per render (-1: unset)
+                val = kw.pop(key)
+                if val < 0:
+                    os.environ.pop(key[4:], None)
+                else:
+                    os.environ[key[4:]] = str(val)
             p = rrt_amd.Context.params(a.nx, a.ny, a.spp, seed=0, time_kernels=True, **kw)
             st = ctx.render_device(p, rgb.data_ptr(), acc.data_ptr())
             if r > 0:
