@@ -53,6 +53,46 @@ def test_jump_is_linear_and_moves_the_state():
     assert not np.array_equal(a, [1, 2, 3, 4])
 
 
+def test_jump_is_two_to_the_64_steps():
+    """rand_xoshiro's Xoshiro128Plus::jump is documented as equivalent to 2^64 calls of next_u32 (the per-thread streams of
+    threadpool.rs:10-19 are made with it).  The generator's state update is linear over GF(2): the 128 x 128 matrix of one step, squared 64
+    times, must map every basis state to what the oracle's jump makes of it.  This pins the four jump constants by
+    arithmetic, not by recollection."""
+    def step(state128):
+        st = np.array([(state128 >> (32 * i)) & 0xFFFFFFFF for i in range(4)], np.uint32)
+        olib().orc_rng_next_u32(st.ctypes.data)
+        return sum(int(v) << (32 * i) for i, v in enumerate(st))
+
+    def jump(state128):
+        st = np.array([(state128 >> (32 * i)) & 0xFFFFFFFF for i in range(4)], np.uint32)
+        olib().orc_rng_jump(st.ctypes.data)
+        return sum(int(v) << (32 * i) for i, v in enumerate(st))
+
+    cols = [step(1 << i) for i in range(128)]          # column i: image of basis state e_i (a 128-bit integer)
+
+    def apply(m, x):                                   # m as columns; x a state
+        y, i = 0, 0
+        while x:
+            if x & 1:
+                y ^= m[i]
+            x >>= 1
+            i += 1
+        return y
+
+    # linearity of one step on a few random states (so that the matrix really is the step)
+    rng = np.random.default_rng(5)
+    for _ in range(20):
+        x = int.from_bytes(rng.bytes(16), "little")
+        assert apply(cols, x) == step(x)
+    m = cols
+    for _ in range(64):                                # m <- m * m, 64 times: the step applied 2^64 times
+        m = [apply(m, c) for c in m]
+    for i in range(128):
+        assert m[i] == jump(1 << i), i
+    x = int.from_bytes(rng.bytes(16), "little")
+    assert apply(m, x) == jump(x)
+
+
 def test_uniform_scales_of_rand():
     lo, sc = C.c_float(), C.c_float()
     for (a, b), bits in {(-1.0, 1.0): 0x40000001, (0.0, 1.0): 0x3F800001, (0.0, 0.5): 0x3F000001, (0.0, 0.0): 0}.items():
