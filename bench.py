@@ -58,10 +58,13 @@ def job_flops(st):
 
 def extend_bytes(st, moving=False):
     """Bytes the extend kernel moves to and from HBM as it is built: per ray the origin (12 B; 16 B with the shutter time in
-    scenes with moving spheres) and the direction with the path id (16 B) in, the 8-byte hit record out.  The live-slot list
-    of a wave whose 256 slots are all alive is the identity and is not read; 1/direction and direction.direction are
-    recomputed, not stored.  (The BVH — 32 B per box test, 16 B per sphere test — is read from the LDS copy, not from HBM.)"""
-    return ((16 if moving else 12) + 16 + 8) * st["rays"]
+    scenes with moving spheres) and the direction with the path id (16 B) in, the 8-byte hit record out, and 12 B of the
+    list plane (a workgroup reads its lists, writes the order in which it takes its pool, camera rays last, and reads a
+    4-byte slot number per hand-out); 1/direction and direction.direction are recomputed, not stored.  (The BVH, 32 B per
+    box test and 16 B per sphere test, is read from the LDS copy, not from HBM.)  The measured figure
+    (counters.bytes_per_ray.extend) is higher: a 128-byte line of a ray plane holds slots under way and fresh slots, which
+    the pool's order takes some 50 us apart, so most lines are fetched twice."""
+    return ((16 if moving else 12) + 16 + 8 + 12) * st["rays"]
 
 
 def extend_bytes_survey(st):
@@ -323,7 +326,7 @@ def main():
                         "bytes_per_ray": round(byts / args.steps / cst["rays"], 1),
                         "survey_pricing": {"bytes_per_ray": 60, "achieved": round(byts_survey / sec / 1e9, 1), "frac": round(byts_survey / sec / 1e9 / HBM_PEAK_GBS, 4)},
                         "note": "extend kernel alone, over its summed (overlapping) launch durations; bytes as the kernel moves them "
-                                "(12 B origin + 16 B direction in, 8 B hit record out; measured: counters.bytes_per_ray.extend), the survey's "
+                                "(12 B origin + 16 B direction in, 8 B hit record out, 12 B of list traffic; measured: counters.bytes_per_ray.extend), the survey's "
                                 "60-byte payload beside it"},
                 "per_ray": {"inner_visits": round(cst["inner_visits"] / cst["rays"], 2), "leaf_tests": round(cst["leaf_tests"] / cst["rays"], 2),
                             "rays_per_path": round(cst["rays"] / cst["paths"], 3)},
