@@ -977,10 +977,11 @@ DEV size_t trail_index(const PathState &P, uint32_t level, uint32_t slot) {
 //   1. classify every slot by what happened to its ray (the extend kernel packs the material kind of the sphere into
 //      the hit record), park the generator states in LDS, and claim path ids for every path that is known to end
 //      (sky, depth limit) with one cursor update;
-//   2. run the in-unit-sphere rejection loop of every Lambertian and metal slot (rng.rs:32-40).  A lane owns the slots
-//      of its column of the list and moves on to its next slot as soon as a sample is accepted, so one lane's
-//      rejections do not hold up a whole tile.  What waits in LDS is the generator state just before the accepted
-//      draw: step 3 repeats that one draw;
+//   2. run the in-unit-sphere rejection loop of every Lambertian and metal slot (rng.rs:32-40).  The slots that want a
+//      sample are one work list of the wave: a lane whose sample has been accepted takes the next slot nobody has taken
+//      (the generator states wait in LDS by list position, so any lane can make any slot's draws), and the loop runs as
+//      long as the wave's total number of draws asks for, not as long as the unluckiest column of four slots.  What
+//      waits in LDS is the generator state just before the accepted draw: step 3 repeats that one draw;
 //   3. per tile: hit record, scatter, sky, trail bookkeeping; an ended path's slot starts its next path right there,
 //      so that each array of the path state gets one store covering (nearly) all 64 neighbouring slots;
 //   4. the few slots whose path was absorbed by a metal sphere (materials.rs:57-60) are refilled, compacted;
@@ -993,6 +994,7 @@ static_assert(RRT_MAT_LAMBERTIAN == CL_LAMB && RRT_MAT_METAL == CL_METAL && RRT_
 
 // LDS words per wave: one 16-byte entry per list position
 constexpr uint32_t kShadeLdsWords = kWaveSlots * 4u;
+constexpr uint32_t kShadeListBytes = kWaveSlots;  // and one byte per list position: the positions that want a sample, compacted (step 2)
 #ifndef RRT_SHADE_TABLE_THREADS
 #define RRT_SHADE_TABLE_THREADS 512
 #endif
@@ -1237,9 +1239,9 @@ DEV NewPath fetch_path(const NewPath &g, int src) {
 
 // One wave shades its list of `count` (> 0) live slots; returns the length of the list it leaves behind.  `l_ent` is the
 // wave's 4 KB of LDS (one 16-byte entry per list position: the slot's generator state; after step 3 the same memory
-// holds step 4's list of slots to refill).
+// holds step 4's list of slots to refill), `l_list` its kShadeListBytes of LDS for step 2's work list.
 template <bool MOVING, bool COUNT, class Tables>
-DEV uint32_t shade_wave(const SceneDev &S, const PathState &P, const BatchDev &Bt, const CameraDev &C, const Tables &T, uint4 *l_ent,
+DEV uint32_t shade_wave(const SceneDev &S, const PathState &P, const BatchDev &Bt, const CameraDev &C, const Tables &T, uint4 *l_ent, uint8_t *l_list,
                         uint32_t wave, uint32_t lane, uint32_t count, uint64_t *wave_stats) {
     constexpr bool TABLES = Tables::kInLds;
     const uint32_t base = wave * kWaveSlots;
@@ -1313,22 +1315,40 @@ DEV uint32_t shade_wave(const SceneDev &S, const PathState &P, const BatchDev &B
 #endif
     // ---- 2. in-unit-sphere rejection ----
     {
-        // bit t set: the slot in column t wants a sample
-        uint32_t todo = 0;
+        // The list positions that want a sample, compacted (one byte each, in LDS).  A lane that has had a sample accepted
+        // takes the next position nobody has taken, whichever lane's column it is in: the generator states wait in LDS by
+        // position, so any lane can run any slot's draws.
+        uint32_t n_want = 0;
 #pragma unroll
-        for (uint32_t t = 0; t < 4u; t++) todo |= ((classes >> (4u * t)) & 15u) <= CL_METAL ? (1u << t) : 0u;
-        uint32_t idx = 0;
+        for (uint32_t t = 0; t < 4u; t++) {
+            const bool want = ((classes >> (4u * t)) & 15u) <= CL_METAL;
+            const uint64_t wm = __ballot(want);
+            if (want) l_list[n_want + prefix_count(wm)] = (uint8_t)(lane + 64u * t);
+            n_want += (uint32_t)__popcll(wm);
+        }
+        uint32_t next = min(64u, n_want);  // first position of the compacted list not taken yet (wave-uniform)
+        bool have = lane < n_want;
+        uint32_t idx = have ? (uint32_t)l_list[lane] : 0u;
         Rng g = {0u, 0u, 0u, 0u};
-        if (todo) { idx = lane + 64u * (uint32_t)(__ffs((int)todo) - 1); const uint4 w = l_ent[idx]; g.s0 = w.x; g.s1 = w.y; g.s2 = w.z; g.s3 = w.w; }
-        while (__ballot(todo != 0u) != 0ull) {
-            if (todo) {
+        if (have) { const uint4 w = l_ent[idx]; g.s0 = w.x; g.s1 = w.y; g.s2 = w.z; g.s3 = w.w; }
+        while (__ballot(have) != 0ull) {
+            bool done = false;
+            if (have) {
                 const Rng before = g;
                 const float x = sample_pm1(g), y = sample_pm1(g), z = sample_pm1(g);
                 if (dot3(mk(x, y, z), mk(x, y, z)) < 1.0f) {
                     l_ent[idx] = make_uint4(before.s0, before.s1, before.s2, before.s3);
-                    todo &= todo - 1u;
-                    if (todo) { idx = lane + 64u * (uint32_t)(__ffs((int)todo) - 1); const uint4 w = l_ent[idx]; g.s0 = w.x; g.s1 = w.y; g.s2 = w.z; g.s3 = w.w; }
+                    done = true;
                 }
+            }
+            const uint64_t dm = __ballot(done);
+            if (dm != 0ull) {
+                const uint32_t k = next + prefix_count(dm);
+                if (done) {
+                    have = k < n_want;
+                    if (have) { idx = (uint32_t)l_list[k]; const uint4 w = l_ent[idx]; g.s0 = w.x; g.s1 = w.y; g.s2 = w.z; g.s3 = w.w; }
+                }
+                next = min(next + (uint32_t)__popcll(dm), n_want);
             }
         }
     }
@@ -1483,7 +1503,7 @@ template <bool MOVING, bool COUNT, bool TABLES>
 __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads, TABLES ? RRT_SHADE_TABLE_WAVES : (!MOVING ? 4 : 3)) void k_shade(SceneDev S, PathState P, BatchDev Bt, CameraDev C,
                                                                                       uint64_t *wave_stats) {
     constexpr uint32_t kThreads = TABLES ? kShadeTableThreads : kBlockThreads;
-    extern __shared__ uint4 lds4[];  // per wave kShadeLdsWords words, then (TABLES) the sphere and material tables
+    extern __shared__ uint4 lds4[];  // per wave kShadeLdsWords words, then (TABLES) the sphere and material tables, then per wave kShadeListBytes
 #ifdef RRT_WAVE_TIMING
     const uint64_t wt0 = wall_clock64();
 #endif
@@ -1507,7 +1527,9 @@ __global__ __launch_bounds__(TABLES ? kShadeTableThreads : kBlockThreads, TABLES
     if (wave >= P.wave_end) return;
     const uint32_t count = rfl(count_word) & kListCountMask;
     if (count == 0) return;
-    shade_wave<MOVING, COUNT, Tables>(S, P, Bt, C, T, lds4 + (threadIdx.x >> 6) * (kShadeLdsWords / 4u), wave, lane, count, wave_stats);
+    uint8_t *lists = reinterpret_cast<uint8_t *>(lds4 + (kThreads / 64u) * (kShadeLdsWords / 4u) + (TABLES ? 2u * S.n_spheres : 0u));  // behind the tables
+    shade_wave<MOVING, COUNT, Tables>(S, P, Bt, C, T, lds4 + (threadIdx.x >> 6) * (kShadeLdsWords / 4u), lists + (threadIdx.x >> 6) * kShadeListBytes, wave, lane, count,
+                                      wave_stats);
 #ifdef RRT_WAVE_TIMING
     if (lane == 0) { uint64_t *w = wave_stats + (size_t)wave * kWaveStatWords; w[13] += wall_clock64() - wt0; w[14] += 1; }
 #endif
@@ -1556,7 +1578,8 @@ __global__ __launch_bounds__(kFinishThreads, 4) void k_finish(SceneDev S, PathSt
         // wave reads through
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        count = shade_wave<MOVING, COUNT, LdsTables>(S, P, Bt, C, T, l_ent, wave, lane, count, wave_stats);
+        count = shade_wave<MOVING, COUNT, LdsTables>(S, P, Bt, C, T, l_ent, reinterpret_cast<uint8_t *>(tab + 2u * S.n_spheres) + (threadIdx.x >> 6) * kShadeListBytes, wave, lane,
+                                                     count, wave_stats);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
@@ -1729,7 +1752,7 @@ void launch_shade(hipStream_t s, const SceneDev &S, const PathState &P, const Ba
     if (P.layout & kLayoutNarrow) {  // set by the host for scenes of at most kShadeTableSpheres spheres (and a depth limit the narrow state holds)
         const uint32_t wpb = kShadeTableThreads / 64u;
         const dim3 g((n_waves + wpb - 1u) / wpb), b(kShadeTableThreads);
-        const size_t lds = (size_t)wpb * kShadeLdsWords * 4u + (size_t)S.n_spheres * 32u;
+        const size_t lds = (size_t)wpb * (kShadeLdsWords * 4u + kShadeListBytes) + (size_t)S.n_spheres * 32u;
         if (moving) {
             if (count) hipLaunchKernelGGL((k_shade<true, true, true>), g, b, lds, s, S, P, B, C, wave_stats);
             else hipLaunchKernelGGL((k_shade<true, false, true>), g, b, lds, s, S, P, B, C, wave_stats);
@@ -1740,7 +1763,7 @@ void launch_shade(hipStream_t s, const SceneDev &S, const PathState &P, const Ba
         return;
     }
     const dim3 g(wave_grid(P)), b(kBlockThreads);
-    const size_t lds = (size_t)(kBlockThreads / 64u) * kShadeLdsWords * 4u;
+    const size_t lds = (size_t)(kBlockThreads / 64u) * (kShadeLdsWords * 4u + kShadeListBytes);
     if (moving) {
         if (count) hipLaunchKernelGGL((k_shade<true, true, false>), g, b, lds, s, S, P, B, C, wave_stats);
         else hipLaunchKernelGGL((k_shade<true, false, false>), g, b, lds, s, S, P, B, C, wave_stats);
@@ -1758,7 +1781,7 @@ int launch_finish(hipStream_t s, const SceneDev &S, const PathState &P, const Ba
                   bool count, uint32_t max_rounds, uint32_t retire_min, uint32_t leaf_min, uint32_t *alive_flag, uint64_t *wave_stats) {
     const uint32_t wpb = kFinishThreads / 64u;
     const dim3 g((P.wave_end - P.wave_begin + wpb - 1u) / wpb), b(kFinishThreads);
-    const size_t lds = (((size_t)S.small_bytes + 15u) & ~(size_t)15u) + (size_t)wpb * kShadeLdsWords * 4u + (size_t)S.n_spheres * 32u;
+    const size_t lds = (((size_t)S.small_bytes + 15u) & ~(size_t)15u) + (size_t)wpb * (kShadeLdsWords * 4u + kShadeListBytes) + (size_t)S.n_spheres * 32u;
     // more than 64 KB of LDS per workgroup has to be asked for once per kernel and device
     static std::mutex mu;
     static std::set<std::pair<int, int>> allowed;
