@@ -61,8 +61,9 @@ constexpr size_t kRadBudgetBytes = size_t(16) << 30;  // per-batch radiance plan
 constexpr uint32_t kMaxBatchPaths = 1u << 30;
 constexpr uint32_t kMaxParts = 4;       // parts of the path pool that run on streams of their own
 // measured: on scenes whose BVH is walked in LDS two parts beat one by 13 % and four by 2 %; on the 1 M-sphere scene
-// (nodes in HBM, latency-bound extend) four beat two by 5 %
-constexpr uint32_t kDefaultPartsLds = 2, kDefaultPartsHbm = 4;
+// (nodes in HBM, latency-bound extend) four beat two by 5 %.  With moving spheres the LDS image is 64 KB and no shade
+// workgroup fits on a CU beside two extend workgroups: three parts beat two by 2.4 % there (book2chap2)
+constexpr uint32_t kDefaultPartsLds = 2, kDefaultPartsLdsMoving = 3, kDefaultPartsHbm = 4;
 constexpr uint32_t kFlagWords = kMaxParts * 32 * 32;  // per part: 32 flag words, one per 128-byte line
 // extend+shade rounds queued between two looks at the alive flags: the first chunk of a render is short (a small render
 // is over after a few rounds), every next one twice as long up to kMaxChunk: each look drains the device (-2.5 % step time
@@ -494,7 +495,7 @@ int render_queued(rrt_ctx *c, const rrt_render_params &P, const RenderTarget &T,
         // that the extend kernel of one part (VALU-bound) runs beside the shade kernel of another (bound by memory
         // latency).  RRT_STREAMS=1..4 picks the number of parts.
         const char *env_streams = std::getenv("RRT_STREAMS");
-        uint32_t n_parts = sd.small_nodes ? kDefaultPartsLds : kDefaultPartsHbm;
+        uint32_t n_parts = sd.small_nodes ? (c->moving ? kDefaultPartsLdsMoving : kDefaultPartsLds) : kDefaultPartsHbm;
         if (env_streams && env_streams[0] >= '1' && env_streams[0] <= '0' + (int)kMaxParts) n_parts = (uint32_t)(env_streams[0] - '0');
         if (n_waves < 32 * n_parts) n_parts = 1;
         PathState part[kMaxParts];
