@@ -67,8 +67,9 @@ constexpr uint32_t kDefaultPartsLds = 2, kDefaultPartsLdsMoving = 3, kDefaultPar
 constexpr uint32_t kFlagWords = kMaxParts * 32 * 32;  // per part: 32 flag words, one per 128-byte line
 // extend+shade rounds queued between two looks at the alive flags: the first chunk of a render is short (a small render
 // is over after a few rounds), every next one twice as long up to kMaxChunk: each look drains the device (-2.5 % step time
-// at 32 against 8 on the headline render, whose 384 rounds then take 14 looks instead of 48)
-constexpr uint32_t kChunk = 8, kMaxChunk = 32;
+// at 32 against 8 on the headline render, whose 384 rounds then take 14 looks instead of 48; another -0.5 % at 64, and
+// nothing more beyond: 128 and 256 measure within 0.1 ms of 64)
+constexpr uint32_t kChunk = 8, kMaxChunk = 64;
 constexpr uint32_t kMaxDepthLimit = 4096;  // depth and trail length share one 32-bit word per path
 // Limits of rrt_render_device_noalloc, which works inside the library's static device array (noalloc.hip): with all three
 // at their maximum the path pool takes 5.5 MB and one sample of radiance plus the sums 7.3 MB of the 16 MiB.
