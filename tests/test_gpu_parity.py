@@ -343,6 +343,34 @@ def test_normal_division_in_and_out_of_the_short_range(gpu_ctx):
         assert ref[2]["hits_lambertian"] > 1000 and ref[2]["hits_dielectric"] > 50 and ref[2]["hits_metal"] > 50, ref[2]
 
 
+@pytest.mark.parametrize("kind", ["all_diffuse", "all_glass", "all_metal"])
+def test_rejection_work_list_extremes(gpu_ctx, kind):
+    """The shade kernel runs the in-unit-sphere rejection loop (rng.rs:32-40) off one work list per wave: the list positions
+    whose slot hit a Lambertian or metal sphere.  Camera inside a closed sphere of one material: every slot of every wave
+    wants a sample (a full work list of 256) nearly always, until the depth limit, or none ever does (glass: an empty list)."""
+    sp = np.zeros((2, 9), np.float32)
+    sp[0, 0:3] = sp[0, 3:6] = (0.0, 0.0, 0.0)
+    sp[1, 0:3] = sp[1, 3:6] = (0.3, 0.1, -1.0)
+    sp[:, 7] = 1.0
+    sp[:, 8] = (50.0, 0.4)
+    m = {"all_diffuse": [0, 0.7, 0.6, 0.5, 0, 0], "all_glass": [2, 1, 1, 1, 0, 1.5], "all_metal": [1, 0.9, 0.8, 0.7, 0.3, 0]}[kind]
+    mt = np.array([m, m], np.float32)
+    mid = np.arange(2, dtype=np.uint32)
+    cam = rrt_amd.camera_from((0, 0, 2), (0, 0, -1), (0, 1, 0), 50.0, 1.25, 0.1, 3.0, 0.0, 0.0)
+    osc = OracleScene.from_arrays(sp, mid, mt, np.zeros((0, 8), np.uint32), cam.as_array())
+    osc.build_bvh(0)
+    _, _, _, nd, _ = scene_arrays_from_oracle(osc)
+    gpu_ctx.upload_scene(sp, mid, mt, nd)
+    gpu_ctx.set_camera(cam)
+    nx, ny, ns = 80, 64, 4   # 20480 paths over an 8192-slot pool: full lists, regenerated in place
+    ref = osc.render(nx, ny, ns, seed=21, max_depth=12, threads=8)
+    gpu = gpu_ctx.render(rrt_amd.Context.params(nx, ny, ns, seed=21, max_depth=12, count_work=True, path_slots=8192))
+    assert_same_image(gpu, ref)
+    hits = {k: ref[2][k] for k in ("hits_lambertian", "hits_metal", "hits_dielectric")}
+    assert sum(1 for v in hits.values() if v) == 1 and max(hits.values()) > 20000, hits
+    assert gpu[2]["depth_cut"] == ref[2]["depth_cut"] and ref[2]["depth_cut"] > 0   # (glass: a few paths are caught inside the small sphere)
+
+
 @pytest.mark.parametrize("max_depth", [50, 300])   # 300: beyond what the narrow per-slot state holds, so the wide layout runs on a small scene
 def test_long_paths_between_two_walls(gpu_ctx, max_depth):
     """A narrow gap between two huge diffuse/metal spheres: paths scatter dozens of times before they see the sky, so the
