@@ -64,6 +64,9 @@ constexpr uint32_t kMaxParts = 4;       // parts of the path pool that run on st
 // (nodes in HBM, latency-bound extend) four beat two by 5 %.  With moving spheres the LDS image is 64 KB and no shade
 // workgroup fits on a CU beside two extend workgroups: three parts beat two by 2.4 % there (book2chap2)
 constexpr uint32_t kDefaultPartsLds = 2, kDefaultPartsLdsMoving = 3, kDefaultPartsHbm = 4;
+// Before the finishing launch (render_impl): plain rounds after the last path is dealt; entries per merged list (below
+// kWaveSlots: a list of kWaveSlots entries is a wave's own slots in order); pools too small for merging to matter
+constexpr uint32_t kFinishDelayRounds = 3, kMergedListLength = kWaveSlots - 1, kMergeMinWaves = 1024;
 constexpr uint32_t kFlagWords = kMaxParts * 32 * 32;  // per part: 32 flag words, one per 128-byte line
 // extend+shade rounds queued between two looks at the alive flags: the first chunk of a render is short (a small render
 // is over after a few rounds), every next one twice as long up to kMaxChunk: each look drains the device (-2.5 % step time
@@ -79,11 +82,12 @@ constexpr uint32_t kNoAllocMaxDepth = 64;
 
 // The pieces of device memory one render call works in: the path pool, its bookkeeping, the framebuffer planes.
 enum WsPiece { WS_RAYA, WS_RAYB, WS_RECENT, WS_RNG, WS_DEPTH, WS_HIT, WS_TRAIL, WS_QUEUE, WS_QCOUNT, WS_WAVE_STATS, WS_CURSORS,
-               WS_FLAGS, WS_STATS_OUT, WS_ACCUM, WS_RAD, WS_PIXEL_MAP, WS_COUNT };
+               WS_FLAGS, WS_STATS_OUT, WS_ACCUM, WS_RAD, WS_PIXEL_MAP, WS_MERGED_QUEUE, WS_MERGED_QCOUNT, WS_LIST_OFFSETS, WS_COUNT };
 
 struct RenderPlan {
     uint32_t npix = 0, batch = 0, slots = 0, n_waves = 0, trail_levels = 1;
     bool want_map = false;
+    bool want_merge = false;  // a second list plane for the lists merged before the finishing launch
     size_t bytes[WS_COUNT] = {};
     // fills bytes[] from the sizes above; returns the total with every piece rounded up to 256 bytes
     size_t size_pieces() {
@@ -93,6 +97,8 @@ struct RenderPlan {
         bytes[WS_QCOUNT] = (size_t)n_waves * 4; bytes[WS_WAVE_STATS] = (size_t)n_waves * kWaveStatWords * 8;
         bytes[WS_CURSORS] = (size_t)kCursorShards * kCursorStride * 4; bytes[WS_FLAGS] = kFlagWords * 4; bytes[WS_STATS_OUT] = kWaveStatWords * 8;
         bytes[WS_ACCUM] = (size_t)npix * 12; bytes[WS_RAD] = (size_t)batch * npix * 16; bytes[WS_PIXEL_MAP] = want_map ? (size_t)npix * 4 : 0;
+        bytes[WS_MERGED_QUEUE] = want_merge ? sl * 4 : 0; bytes[WS_MERGED_QCOUNT] = want_merge ? (size_t)n_waves * 4 : 0;
+        bytes[WS_LIST_OFFSETS] = want_merge ? ((size_t)n_waves + 1) * 4 : 0;
         size_t total = 0;
         for (size_t b : bytes) total += (b + 255) & ~size_t(255);
         return total;
@@ -453,6 +459,7 @@ int render_queued(rrt_ctx *c, const rrt_render_params &P, const RenderTarget &T,
         pl.slots = slots;
         pl.n_waves = slots / kWaveSlots;
         pl.batch = batch;
+        pl.want_merge = !no_alloc;
         void *piece[WS_COUNT] = {};
         if (no_alloc) {
             // as many samples per batch as the workspace holds beside the path pool
@@ -511,6 +518,16 @@ int render_queued(rrt_ctx *c, const rrt_render_params &P, const RenderTarget &T,
         // (not for the entry point that must allocate nothing: the finishing kernel spills a few registers, and the runtime
         // allocates the memory spills go to when such a kernel is first launched)
         const bool can_finish = !no_alloc && finish_fits(sd, ps) && !std::getenv("RRT_NO_FINISH");
+        // Between the last path being dealt and the finishing launch: a few more plain rounds (what is left of a full pool is
+        // still best served by the two kernels), then the thinned-out lists are merged into full ones for the first waves
+        // (kernels.h: launch_merge_lists), so that the finishing launch is a fraction of the pool's workgroups, all at work,
+        // instead of every workgroup of the pool waiting for its longest path.  RRT_FINISH_MERGE=0: the finishing launch at
+        // once, on the lists as they are; RRT_FINISH_DELAY: the number of rounds.
+        uint32_t finish_delay = kFinishDelayRounds;
+        if (const char *e = std::getenv("RRT_FINISH_DELAY")) finish_delay = (uint32_t)std::min(64, std::max(0, std::atoi(e)));
+        bool merge_lists = pl.want_merge && n_waves >= kMergeMinWaves;
+        if (const char *e = std::getenv("RRT_FINISH_MERGE")) merge_lists = merge_lists && e[0] != '0';
+        PathState ps_finish = ps;  // what the finishing launch works on
         for (uint32_t s0 = 0; s0 < ns_local; s0 += batch) {
             const uint32_t nb = std::min(batch, ns_local - s0);
             BatchDev bd{};
@@ -530,36 +547,52 @@ int render_queued(rrt_ctx *c, const rrt_render_params &P, const RenderTarget &T,
             // Once every path of the batch has been dealt (at once, if the batch is no larger than the pool), what is left
             // thins out over up to max_depth more rounds: where the scene allows it, one launch runs them all.
             bool dealt = can_finish && (uint64_t)bd.n_paths <= slots;
+            bool merge_pending = false;  // the next finishing launch is preceded by the plain rounds and the merge
+            ps_finish = ps;
             uint64_t claimed_before = std::min<uint64_t>(slots, bd.n_paths);  // raygen deals the first paths
             for (;;) {
                 HIP_TRY(hipMemsetAsync(flags, 0, kFlagWords * 4, s));
+                // `rounds` rounds of extend + shade on every part's stream, joined on `s`; the last round reports which waves still
+                // hold paths if `report` is set
+                auto queue_rounds = [&](uint32_t rounds, bool report) -> int {
+                    if (n_parts > 1) {
+                        HIP_TRY(hipEventRecord(c->ev_fork, s));
+                        for (uint32_t h = 1; h < n_parts; h++) HIP_TRY(hipStreamWaitEvent(part_stream[h], c->ev_fork, 0));
+                    }
+                    for (uint32_t it = 0; it < rounds; it++) {
+                        for (uint32_t h = 0; h < n_parts; h++) {
+                            hipStream_t sp = part_stream[h];
+                            bool time_kernels = time_stride != 0 && it % time_stride == 0;
+                            if (time_kernels) {
+                                while (c->kev.size() < kev_used + 2) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); c->kev.push_back(ev); }
+                                HIP_TRY(hipEventRecord(c->kev[kev_used], sp));
+                            }
+                            launch_extend(sp, sd, part[h], c->moving, count, retire_min, leaf_min, wstats);
+                            if (time_kernels) { HIP_TRY(hipEventRecord(c->kev[kev_used + 1], sp)); kev_used += 2; }
+                            bd.alive_flag = report && it + 1 == rounds ? flags + h * 1024 : nullptr;  // only the chunk's last round reports
+                            launch_shade(sp, sd, part[h], bd, c->cam, c->moving, count, wstats);
+                        }
+                    }
+                    st.iterations += rounds;
+                    for (uint32_t h = 1; h < n_parts; h++) { HIP_TRY(hipEventRecord(c->ev_join[h - 1], part_stream[h])); HIP_TRY(hipStreamWaitEvent(s, c->ev_join[h - 1], 0)); }
+                    return RRT_OK;
+                };
                 if (dealt) {
-                    if (launch_finish(s, sd, ps, bd, c->cam, c->moving, count, P.max_depth + 2u, retire_min, leaf_min, flags, wstats))
+                    if (merge_pending) {
+                        merge_pending = false;
+                        if (finish_delay) { const int rc = queue_rounds(finish_delay, false); if (rc != RRT_OK) return rc; }
+                        ps_finish.queue = static_cast<uint32_t *>(at(WS_MERGED_QUEUE));
+                        ps_finish.qcount = static_cast<uint32_t *>(at(WS_MERGED_QCOUNT));
+                        launch_merge_lists(s, ps, ps_finish.queue, ps_finish.qcount, static_cast<uint32_t *>(at(WS_LIST_OFFSETS)), kMergedListLength);
+                    }
+                    if (launch_finish(s, sd, ps_finish, bd, c->cam, c->moving, count, P.max_depth + 2u, retire_min, leaf_min, flags, wstats))
                         return fail(RRT_ERR_HIP, "rrt_render: the finishing kernel's LDS request was refused");
                     st.iterations += 1;
                 } else {
-                if (n_parts > 1) {
-                    HIP_TRY(hipEventRecord(c->ev_fork, s));
-                    for (uint32_t h = 1; h < n_parts; h++) HIP_TRY(hipStreamWaitEvent(part_stream[h], c->ev_fork, 0));
-                }
-                for (uint32_t it = 0; it < chunk; it++) {
-                    for (uint32_t h = 0; h < n_parts; h++) {
-                        hipStream_t sp = part_stream[h];
-                        bool time_kernels = time_stride != 0 && it % time_stride == 0;
-                        if (time_kernels) {
-                            while (c->kev.size() < kev_used + 2) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); c->kev.push_back(ev); }
-                            HIP_TRY(hipEventRecord(c->kev[kev_used], sp));
-                        }
-                        launch_extend(sp, sd, part[h], c->moving, count, retire_min, leaf_min, wstats);
-                        if (time_kernels) { HIP_TRY(hipEventRecord(c->kev[kev_used + 1], sp)); kev_used += 2; }
-                        bd.alive_flag = it + 1 == chunk ? flags + h * 1024 : nullptr;  // only the chunk's last round reports
-                        launch_shade(sp, sd, part[h], bd, c->cam, c->moving, count, wstats);
-                    }
-                }
-                st.iterations += chunk;
-                rounds_done = chunk;
-                chunk = std::min(kMaxChunk, chunk * 2u);
-                for (uint32_t h = 1; h < n_parts; h++) { HIP_TRY(hipEventRecord(c->ev_join[h - 1], part_stream[h])); HIP_TRY(hipStreamWaitEvent(s, c->ev_join[h - 1], 0)); }
+                    const int rc = queue_rounds(chunk, true);
+                    if (rc != RRT_OK) return rc;
+                    rounds_done = chunk;
+                    chunk = std::min(kMaxChunk, chunk * 2u);
                 }
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipMemcpyAsync(c->h_flags, flags, kFlagWords * 4, hipMemcpyDeviceToHost, s));
@@ -585,6 +618,7 @@ int render_queued(rrt_ctx *c, const rrt_render_params &P, const RenderTarget &T,
                         if (left < (double)chunk) chunk = std::max(1u, (uint32_t)std::ceil(left));
                     }
                     claimed_before = claimed;
+                    if (dealt && merge_lists && any) merge_pending = true;
                 }
                 if (T.progress) {
                     // Paths handed out so far, less those that may still be in flight, are finished; a pixel counts as

@@ -124,6 +124,10 @@ void launch_shade(hipStream_t s, const SceneDev &S, const PathState &P, const Ba
 // max_rounds turns; a wave that stops with paths left raises alive_flag).  finish_fits says whether the scene and the
 // state layout allow it (BVH image and tables in LDS together); launch_finish returns nonzero if HIP refused the set-up.
 bool finish_fits(const SceneDev &S, const PathState &P);
+// The live lists of all of P's waves (P.wave_begin == 0) concatenated and cut into lists of list_len (< kWaveSlots) entries
+// for the first waves, in a second list plane (merged_queue: as large as P.queue; merged_qcount: one word per wave;
+// offsets: one word per wave and one more): what the finishing launch runs on once the lists have thinned out.
+void launch_merge_lists(hipStream_t s, const PathState &P, uint32_t *merged_queue, uint32_t *merged_qcount, uint32_t *offsets, uint32_t list_len);
 int launch_finish(hipStream_t s, const SceneDev &S, const PathState &P, const BatchDev &B, const CameraDev &C, bool moving,
                   bool count, uint32_t max_rounds, uint32_t retire_min, uint32_t leaf_min, uint32_t *alive_flag, uint64_t *wave_stats);
 // accum[3][npix] += radiance of the batch's paths, sample by sample in order (lib.rs:96-103)

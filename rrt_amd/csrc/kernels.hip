@@ -1586,6 +1586,55 @@ __global__ __launch_bounds__(kFinishThreads, 4) void k_finish(SceneDev S, PathSt
     if (count != 0u && lane == 0 && alive_flag) alive_flag[(wave & 31u) * 32u] = 1u;
 }
 
+// ---- Merging the live lists before the finishing launch ----
+//
+// When the last path of a batch has been dealt, every list thins out from round to round, and a launch that gives every
+// list a wave of its own keeps every workgroup of the pool busy for as long as its longest path lasts.  A list is nothing
+// but the slot numbers a wave works on: the lists' entries are concatenated (in wave order) and cut into lists of
+// `list_len` entries for the first waves, in a second list plane, and the finishing launch runs on those: a fraction of
+// the workgroups, full of work.  No path state moves.  list_len is below kWaveSlots: a list of kWaveSlots entries is taken
+// to be the wave's own slots in order.
+__global__ __launch_bounds__(1024) void k_list_offsets(const uint32_t *qcount, uint32_t n_waves, uint32_t *offsets) {
+    __shared__ uint32_t part[1024];  // one workgroup: offsets[w] = entries in the lists before list w, offsets[n_waves] = all
+    const uint32_t per = (n_waves + 1023u) / 1024u;
+    const uint32_t lo = min(n_waves, threadIdx.x * per), hi = min(n_waves, lo + per);
+    uint32_t sum = 0;
+    for (uint32_t w = lo; w < hi; w++) sum += qcount[w] & kListCountMask;
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024u; off <<= 1) {
+        const uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+    for (uint32_t w = lo; w < hi; w++) { offsets[w] = run; run += qcount[w] & kListCountMask; }
+    if (threadIdx.x == 1023u) offsets[n_waves] = part[1023];
+}
+
+__global__ __launch_bounds__(kBlockThreads) void k_merge_lists(PathState P, uint32_t *merged_queue, uint32_t *merged_qcount, const uint32_t *offsets, uint32_t list_len) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * kBlockThreads + threadIdx.x) >> 6;
+    const uint32_t n_waves = P.wave_end;
+    if (wave >= n_waves) return;
+    const uint32_t count = rfl(P.qcount[wave]) & kListCountMask, before = rfl(offsets[wave]), total = rfl(offsets[n_waves]);
+#pragma unroll
+    for (uint32_t k = 0; k < kWaveSlots / 64u; k++) {
+        const uint32_t pos = lane + 64u * k;
+        if (pos < count) {
+            const uint32_t slot = count == kWaveSlots ? wave * kWaveSlots + pos : P.queue[wave * kWaveSlots + pos];  // a full list: the wave's slots in order
+            const uint32_t at = before + pos;
+            const uint32_t list = at / list_len;
+            merged_queue[list * kWaveSlots + (at - list * list_len)] = slot;
+        }
+    }
+    if (lane == 0) {  // the length of merged list number `wave`
+        const uint64_t begin = (uint64_t)wave * list_len;
+        merged_qcount[wave] = total > begin ? (uint32_t)min<uint64_t>(list_len, total - begin) : 0u;
+    }
+}
+
 __global__ void k_accumulate(float *accum, uint32_t npix, const float4 *rad, uint32_t n_samples, int first) {
     const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= npix) return;
@@ -1809,6 +1858,11 @@ int launch_finish(hipStream_t s, const SceneDev &S, const PathState &P, const Ba
         else hipLaunchKernelGGL((k_finish<false, false>), g, b, lds, s, S, P, Bq, C, max_rounds, retire_min, leaf_min, alive_flag, wave_stats);
     }
     return 0;
+}
+
+void launch_merge_lists(hipStream_t s, const PathState &P, uint32_t *merged_queue, uint32_t *merged_qcount, uint32_t *offsets, uint32_t list_len) {
+    hipLaunchKernelGGL(k_list_offsets, dim3(1), dim3(1024), 0, s, P.qcount, P.wave_end, offsets);
+    hipLaunchKernelGGL(k_merge_lists, dim3((P.wave_end + 3u) / 4u), dim3(kBlockThreads), 0, s, P, merged_queue, merged_qcount, offsets, list_len);
 }
 
 void launch_accumulate(hipStream_t s, float *accum, uint32_t npix, const float4 *rad, uint32_t n_samples,
