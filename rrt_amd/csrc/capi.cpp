@@ -57,7 +57,9 @@ struct DevBuf {
 };
 
 constexpr uint32_t kDefaultSlots = 14336u * kWaveSlots;  // 3.5 Mi: the headline render is 1-2 % faster than with 4 Mi, the other configurations within 1 % (profiles/r03_sweep_slots.txt)
-constexpr size_t kRadBudgetBytes = size_t(16) << 30;  // per-batch radiance planes; HBM is 288 GB (capped by what is free)
+// per-batch radiance planes; HBM is 288 GB (capped by half of what is free).  Larger batches were measured and buy nothing:
+// 3840x2160x1024 takes 1.38 s in two batches of 64 GiB as in eight of 16 GiB.
+constexpr size_t kRadBudgetBytes = size_t(16) << 30;
 constexpr uint32_t kMaxBatchPaths = 1u << 30;
 constexpr uint32_t kMaxParts = 4;       // parts of the path pool that run on streams of their own
 // measured: on scenes whose BVH is walked in LDS two parts beat one by 13 % and four by 2 %; on the 1 M-sphere scene
@@ -451,7 +453,7 @@ int render_queued(rrt_ctx *c, const rrt_render_params &P, const RenderTarget &T,
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) rad_budget = std::min(rad_budget, std::max<size_t>(free_b / 2 + c->ws[WS_RAD].cap, size_t(64) << 20));
         }
-        uint32_t batch = P.batch_samples ? P.batch_samples : (uint32_t)std::max<size_t>(1, rad_budget / ((size_t)npix * 16));
+        uint32_t batch = P.batch_samples ? P.batch_samples : (uint32_t)std::min<size_t>(0xFFFFFFFFu, std::max<size_t>(1, rad_budget / ((size_t)npix * 16)));
         batch = std::min(batch, ns_local);
         batch = std::min<uint32_t>(batch, std::max<uint32_t>(1, kMaxBatchPaths / npix));
         slots = std::min<uint64_t>(slots, ((uint64_t)batch * npix + kWaveSlots - 1) / kWaveSlots * kWaveSlots);
