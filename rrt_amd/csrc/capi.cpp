@@ -524,11 +524,11 @@ int render_queued(rrt_ctx *c, const rrt_render_params &P, const RenderTarget &T,
         // still best served by the two kernels), then the thinned-out lists are merged into full ones for the first waves
         // (kernels.h: launch_merge_lists), so that the finishing launch is a fraction of the pool's workgroups, all at work,
         // instead of every workgroup of the pool waiting for its longest path.  RRT_FINISH_MERGE=0: the finishing launch at
-        // once, on the lists as they are; RRT_FINISH_DELAY: the number of rounds.
+        // once, on the lists as they are (2: merge whatever the size of the pool); RRT_FINISH_DELAY: the number of rounds.
         uint32_t finish_delay = kFinishDelayRounds;
         if (const char *e = std::getenv("RRT_FINISH_DELAY")) finish_delay = (uint32_t)std::min(64, std::max(0, std::atoi(e)));
         bool merge_lists = pl.want_merge && n_waves >= kMergeMinWaves;
-        if (const char *e = std::getenv("RRT_FINISH_MERGE")) merge_lists = merge_lists && e[0] != '0';
+        if (const char *e = std::getenv("RRT_FINISH_MERGE")) merge_lists = pl.want_merge && (e[0] == '2' || (merge_lists && e[0] != '0'));  // 2: pools of any size
         PathState ps_finish = ps;  // what the finishing launch works on
         for (uint32_t s0 = 0; s0 < ns_local; s0 += batch) {
             const uint32_t nb = std::min(batch, ns_local - s0);

@@ -1619,6 +1619,9 @@ __global__ __launch_bounds__(kBlockThreads) void k_merge_lists(PathState P, uint
     const uint32_t n_waves = P.wave_end;
     if (wave >= n_waves) return;
     const uint32_t count = rfl(P.qcount[wave]) & kListCountMask, before = rfl(offsets[wave]), total = rfl(offsets[n_waves]);
+    // Lists of list_len entries hold a little less than the pool: while the lists are still (nearly) full there is nothing to
+    // merge, and every list goes into the second plane as it is.
+    const bool merge = (uint64_t)total <= (uint64_t)n_waves * list_len;
 #pragma unroll
     for (uint32_t k = 0; k < kWaveSlots / 64u; k++) {
         const uint32_t pos = lane + 64u * k;
@@ -1626,12 +1629,12 @@ __global__ __launch_bounds__(kBlockThreads) void k_merge_lists(PathState P, uint
             const uint32_t slot = count == kWaveSlots ? wave * kWaveSlots + pos : P.queue[wave * kWaveSlots + pos];  // a full list: the wave's slots in order
             const uint32_t at = before + pos;
             const uint32_t list = at / list_len;
-            merged_queue[list * kWaveSlots + (at - list * list_len)] = slot;
+            merged_queue[merge ? list * kWaveSlots + (at - list * list_len) : wave * kWaveSlots + pos] = slot;
         }
     }
     if (lane == 0) {  // the length of merged list number `wave`
         const uint64_t begin = (uint64_t)wave * list_len;
-        merged_qcount[wave] = total > begin ? (uint32_t)min<uint64_t>(list_len, total - begin) : 0u;
+        merged_qcount[wave] = !merge ? count : (total > begin ? (uint32_t)min<uint64_t>(list_len, total - begin) : 0u);
     }
 }
 

@@ -227,6 +227,38 @@ def test_finishing_launch_and_plain_rounds_agree(gpu_ctx, monkeypatch):
     monkeypatch.delenv("RRT_NO_FINISH", raising=False)
 
 
+@pytest.mark.parametrize("delay", ["0", "3"])
+def test_lists_merged_before_the_finishing_launch(gpu_ctx, monkeypatch, delay):
+    """Once the last path of a batch is dealt the host queues a few more plain rounds, merges the thinned-out live lists into
+    full ones for the first waves and runs the finishing launch on those (a list is only the slot numbers a wave works on).
+    Pools as small as a test's skip the merge unless RRT_FINISH_MERGE=2 asks for it: same image and work counters with and
+    without, for one batch and for several."""
+    for scene, moving in (("chap12", False), ("book2chap2", True)):
+        osc = OracleScene.build(SCENES[scene], 160, 100, seed=3)
+        upload_from_oracle(gpu_ctx, osc)
+        ref = osc.render(160, 100, 12, seed=9, threads=8)
+        for batch in (0, 5):
+            for merge in ("2", "0"):
+                monkeypatch.setenv("RRT_FINISH_MERGE", merge)
+                monkeypatch.setenv("RRT_FINISH_DELAY", delay)
+                gpu = gpu_ctx.render(rrt_amd.Context.params(160, 100, 12, seed=9, path_slots=64 * 1024, batch_samples=batch, count_work=True))
+                assert_same_image(gpu, ref)
+                for k in ("rays", "inner_visits", "leaf_tests", "paths", "sky_misses", "depth_cut"):
+                    assert gpu[2][k] == ref[2][k], (scene, batch, merge, k)
+    # lists that are still full when the merge runs do not fit lists of 255: they are taken as they are (a pool of one list,
+    # and one of 40, merged at once)
+    osc = OracleScene.build(SCENES["chap12"], 68, 65, seed=59)
+    upload_from_oracle(gpu_ctx, osc)
+    ref = osc.render(68, 65, 6, seed=5, max_depth=120, threads=8)
+    monkeypatch.setenv("RRT_FINISH_MERGE", "2")
+    monkeypatch.setenv("RRT_FINISH_DELAY", delay)
+    for slots in (256, 40 * 256):
+        gpu = gpu_ctx.render(rrt_amd.Context.params(68, 65, 6, seed=5, max_depth=120, path_slots=slots, batch_samples=1))
+        assert_same_image(gpu, ref)
+    monkeypatch.delenv("RRT_FINISH_MERGE", raising=False)
+    monkeypatch.delenv("RRT_FINISH_DELAY", raising=False)
+
+
 def test_tile_sharding_composes_to_the_unsharded_image(gpu_ctx):
     nx, ny, ns = 100, 37, 6   # not a multiple of the 32x8 tile in either direction
     osc = OracleScene.build(SCENES["chap12"], nx, ny, seed=0)

@@ -35,6 +35,8 @@ while time.time() < t_end:
         os.environ["RRT_NO_FINISH"] = "1"  # rounds to the end instead of the finishing launch
     else:
         os.environ.pop("RRT_NO_FINISH", None)
+    os.environ["RRT_FINISH_MERGE"] = str(int(rng.choice([0, 1, 2, 2])))  # 2: the live lists are merged before the finishing launch whatever the pool's size
+    os.environ["RRT_FINISH_DELAY"] = str(int(rng.choice([0, 1, 3, 3, 7])))
     osc = OracleScene.build(kind, nx, ny, seed=scene_seed, half=half)
     sp, mid, mt, nd, cam21 = scene_arrays_from_oracle(osc)
     ctx.upload_scene(sp, mid, mt, nd)
@@ -43,7 +45,7 @@ while time.time() < t_end:
     p = rrt_amd.Context.params(nx, ny, ns, seed=seed, max_depth=depth, path_slots=slots, batch_samples=batch, force_hbm_bvh=force_hbm,
                                count_work=bool(rng.integers(0, 2)))
     rgb, acc, st = ctx.render(p)
-    tag = f"kind {kind} half {half} {nx}x{ny}x{ns} depth {depth} slots {slots} batch {batch} parts {parts} hbm {force_hbm} seed {seed}/{scene_seed}"
+    tag = f"kind {kind} half {half} {nx}x{ny}x{ns} depth {depth} slots {slots} batch {batch} parts {parts} hbm {force_hbm} seed {seed}/{scene_seed} merge {os.environ['RRT_FINISH_MERGE']} delay {os.environ['RRT_FINISH_DELAY']} no_finish {os.environ.get('RRT_NO_FINISH', '0')}"
     ok = np.array_equal(acc.view(np.uint32), acc_o.view(np.uint32)) and np.array_equal(rgb, rgb_o) and st["rays"] == ct["rays"]
     if not ok:
         print("MISMATCH", tag, flush=True)
