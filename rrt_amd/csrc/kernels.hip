@@ -611,6 +611,10 @@ DEV uint32_t visit_leaf(const WideStore<MOVING, COUNT> &st, uint32_t cur, RayCtx
     return st.pop(r, k, n_inner);
 }
 
+// A wave's statistics are added to its row by atomics that return nothing: a plain `+=` is a load the wave has to wait for
+// before it can store and end, a memory round trip at the very end of every wave of every launch.
+DEV void stat_add(uint64_t *word, uint64_t v) { (void)__hip_atomic_fetch_add(word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 DEV uint64_t wave_sum_u64(uint64_t v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
@@ -738,14 +742,14 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
     if (COUNT) {
         const uint64_t si = wave_sum_u64(n_inner), sl = wave_sum_u64(n_leaf);
         if (lane == 0) {
-            stt[ST_INNER] += si; stt[ST_LEAF] += sl;
+            stat_add(&stt[ST_INNER], si); stat_add(&stt[ST_LEAF], sl);
 #ifndef RRT_SHADE_TIMING
             stt[10] += d_desc_iters; stt[11] += d_desc_lanes; stt[12] += d_leaf_iters; stt[13] += d_leaf_lanes; stt[14] += d_retires;
             stt[15] += d_retire_lanes;
 #endif
         }
     }
-    if (lane == 0) stt[ST_RAYS] += n_taken;
+    if (lane == 0) stat_add(&stt[ST_RAYS], n_taken);
 }
 
 // (kLayoutFreshApart) The order in which a workgroup's pool of full lists is taken: the slots whose paths are under way, list
@@ -961,7 +965,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_raygen(PathState P, BatchDev 
     if (lane == 0) {
         P.qcount[wave] = out_count | (out_count << kListFreshShift);  // every path of the list has just started
         if (out_count && Bt.alive_flag) Bt.alive_flag[(wave & 31u) * 32u] = 1u;  // 32 lines share the traffic
-        wave_stats[(size_t)wave * kWaveStatWords + ST_PATHS] += out_count;
+        stat_add(&wave_stats[(size_t)wave * kWaveStatWords + ST_PATHS], out_count);
     }
 }
 
@@ -1487,13 +1491,13 @@ DEV uint32_t shade_wave(const SceneDev &S, const PathState &P, const BatchDev &B
         P.qcount[wave] = out_count | (n_fresh << kListFreshShift);
         if (out_count && Bt.alive_flag) Bt.alive_flag[(wave & 31u) * 32u] = 1u;  // 32 lines share the traffic
         uint64_t *st = wave_stats + (size_t)wave * kWaveStatWords;
-        st[ST_PATHS] += n_started + n_refilled;
+        stat_add(&st[ST_PATHS], n_started + n_refilled);
 #ifdef RRT_SHADE_TIMING
         { const uint64_t tk5 = __builtin_readcyclecounter(); st[10] += tk1 - tk0; st[11] += tk2 - tk1; st[12] += tk3 - tk2; st[13] += tk4 - tk3; st[14] += tk5 - tk4; st[15] += 1; }
 #endif
         if (COUNT) {
-            st[ST_HL] += c_ev[0]; st[ST_HM] += c_ev[1]; st[ST_HD] += c_ev[2]; st[ST_SKY] += c_ev[3];
-            st[ST_DEPTHCUT] += c_ev[4]; st[ST_ABSORBED] += (uint32_t)n_need;
+            stat_add(&st[ST_HL], c_ev[0]); stat_add(&st[ST_HM], c_ev[1]); stat_add(&st[ST_HD], c_ev[2]); stat_add(&st[ST_SKY], c_ev[3]);
+            stat_add(&st[ST_DEPTHCUT], c_ev[4]); stat_add(&st[ST_ABSORBED], (uint32_t)n_need);
         }
     }
     return out_count;
