@@ -207,8 +207,9 @@ struct RayCtx {
     float time, f_ray;
     float tmin, tmax;
     uint32_t oct;   // bit k set: 1/d[k] < 0 (acceleration.rs:230-231)
-    // for the compact LDS image: byte offset inside an inner node of the (near, far) plane pair of each axis and of the
-    // (near child | exit) word of the ray's octant, and inside a leaf of the octant's exit link
+    // for the compact LDS image: byte offset inside an inner node of the (near, far) pair of x planes (what the walk's reference
+    // to an inner node points at), from there to the pairs of y and z planes and to the (near child | exit) word of the ray's
+    // octant, and inside a leaf to the octant's exit link
     uint32_t cx, cy, cz, link, leaf_link;
     uint32_t best;  // store-specific handle of the closest leaf so far
 };
@@ -218,8 +219,10 @@ DEV V3 origin(const RayCtx &r) { return mk(r.ox.x, r.oy.x, r.oz.x); }
 DEV void ray_finish(RayCtx &r, float tmin, float tmax, const SceneDev &S, bool uniform_times) {
     const uint32_t nx = r.ox.y < 0.0f ? 1u : 0u, ny = r.oy.y < 0.0f ? 1u : 0u, nz = r.oz.y < 0.0f ? 1u : 0u;  // acceleration.rs:230-231
     r.oct = nx | (ny << 1) | (nz << 2);
-    r.cx = nx << 3; r.cy = 16u + (ny << 3); r.cz = 32u + (nz << 3);
-    r.link = kSmallLinkOffset + (r.oct << 2);
+    // the walk's reference to an inner node already points at the ray's pair of x planes (scene_layout.h): the other offsets
+    // count from there
+    r.cx = nx << 3; r.cy = 16u + (ny << 3) - r.cx; r.cz = 32u + (nz << 3) - r.cx;
+    r.link = kSmallLinkOffset + (r.oct << 2) - r.cx;
     r.leaf_link = S.small_leaf_links + (r.oct << 1);
     r.f_ray = uniform_times ? (r.time - S.u_time0) / S.u_dt : 0.0f;  // center_at's factor when every moving sphere shares its shutter interval
     r.tmin = tmin;
@@ -336,7 +339,7 @@ struct LdsStore {
     DEV uint32_t root() const { return root16; }
     DEV uint32_t end() const { return end16; }
     DEV bool uniform_times() const { return MOVING; }  // the compact copy exists only for scenes with one shutter interval
-    DEV uint32_t start(RayCtx &, NoStack &, uint32_t &) const { return root(); }
+    DEV uint32_t start(RayCtx &r, NoStack &, uint32_t &) const { return root16 < end16 ? root16 + r.cx : root16; }  // an inner root: at the ray's pair of x planes
     typedef const __attribute__((address_space(3))) uint32_t *LdsWordPtr;
     typedef const __attribute__((address_space(3))) float *LdsFloatPtr;
     typedef const __attribute__((address_space(3))) uint16_t *LdsHalfPtr;
@@ -349,7 +352,7 @@ struct LdsStore {
     // the axis reads (near, far) directly, with an address instead of a select.  `links` comes back as near child | exit
     // link << 16 for the ray's octant.
     DEV void inner(uint32_t cur, const RayCtx &r, f32x2 &bx, f32x2 &by, f32x2 &bz, uint32_t &links) const {
-        bx = pair_at(cur + r.cx); by = pair_at(cur + r.cy); bz = pair_at(cur + r.cz);
+        bx = pair_at(cur); by = pair_at(cur + r.cy); bz = pair_at(cur + r.cz);
         links = *words(cur + r.link);
     }
     DEV void leaf(uint32_t cur, const RayCtx &r, V3 &c, float &rr, uint32_t &handle, uint32_t &exit_ref) const {

@@ -204,6 +204,12 @@ int build_scene_layout(const rrt_sphere_soa *sp, const rrt_material_soa *mt, con
             else if (out.node_kind[i] == 2) off[i] = static_cast<uint32_t>(end_off) + 4u + (li++) * leaf_bytes;
         }
         auto ref16 = [&](uint32_t r) -> uint32_t { return r == kRefEnd ? static_cast<uint32_t>(end_off) : off[r & kRefIndexMask]; };
+        // a link that octant `o` follows to an inner node points at the (near, far) pair of that node's x planes for the
+        // octant: 8 bytes in for rays that are negative along x (scene_layout.h)
+        auto link16 = [&](uint32_t r, uint32_t o) -> uint32_t {
+            const uint32_t a = ref16(r);
+            return a < end_off ? a + ((o & 1u) ? 8u : 0u) : a;
+        };
         out.small_bytes = static_cast<uint32_t>(total);
         out.small_end = static_cast<uint32_t>(end_off);
         out.small_leaf_links = leaf_bytes - 16u;
@@ -218,7 +224,7 @@ int build_scene_layout(const rrt_sphere_soa *sp, const rrt_material_soa *mt, con
                 const uint32_t left = ref16(w[7]), right = ref16(w[6] & (kRefLeafBit | kRefIndexMask));
                 for (uint32_t o = 0; o < 8; o++) {
                     const uint32_t near_ref = ((o >> axis) & 1u) ? right : left;  // acceleration.rs:253-267
-                    s[kSmallLinkOffset / 4u + o] = near_ref | (ref16(w[8 + o]) << 16);
+                    s[kSmallLinkOffset / 4u + o] = (near_ref < end_off ? near_ref + ((o & 1u) ? 8u : 0u) : near_ref) | (link16(w[8 + o], o) << 16);
                 }
             } else {
                 for (int k = 0; k < 5; k++) s[k] = w[k];
@@ -231,7 +237,7 @@ int build_scene_layout(const rrt_sphere_soa *sp, const rrt_material_soa *mt, con
                     }
                     links = s + 9;
                 }
-                for (int o = 0; o < 8; o += 2) links[o / 2] = ref16(w[8 + o]) | (ref16(w[8 + o + 1]) << 16);
+                for (uint32_t o = 0; o < 8; o += 2) links[o / 2] = link16(w[8 + o], o) | (link16(w[8 + o + 1], o + 1u) << 16);
             }
         }
         out.small_root = ref16(out.root_ref);

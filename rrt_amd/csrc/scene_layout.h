@@ -28,7 +28,11 @@ constexpr uint32_t kLeafKindShift = 30;
 // Compact layout for scenes small enough to live in a workgroup's LDS.  A 16-bit reference is the node's byte offset
 // in the image (= its LDS address: the image starts at LDS address 0).  Inner nodes (80 bytes) come first, then one
 // unused word whose offset is the reference that means "nothing left to visit", then the leaves (36 bytes, or 52 in a
-// scene with moving spheres); so `ref < end` is an inner node and `ref > end` a leaf.
+// scene with moving spheres); so `ref < end` is an inner node and `ref > end` a leaf.  The links INSIDE the image (near
+// child, exit links) are made for the octant that follows them: one that leads to an inner node is that node's offset plus
+// 8 for the octants whose rays are negative along x, i.e. the address of the (near, far) pair of its x planes for the ray,
+// so that the walk reads the pair at the reference itself and reaches the other two pairs and the link word by three
+// per-ray offsets from there, not four from the node's start.  small_root is the plain offset.
 constexpr uint32_t kSmallInnerBytes = 80;
 constexpr uint32_t kSmallLeafBytes = 36;        // centre, radius^2, sphere word, 8 exit links of 16 bits
 constexpr uint32_t kSmallLeafBytesMoving = 52;  // + moving flag and centre1 - centre0
