@@ -115,7 +115,7 @@ struct rrt_ctx {
     hipEvent_t ev_fork = nullptr, ev_join[kMaxParts - 1] = {};
     hipDeviceProp_t prop{};
     // scene
-    DevBuf nodes, small_nodes, top_nodes, wide, wide_top, sph, motion, motion_dt, sph_info, prim_att;
+    DevBuf nodes, small_nodes, top_nodes, wide, sph, motion, motion_dt, sph_info, prim_att;
     SceneDev sd{};
     bool has_scene = false, moving = false;
     uint32_t n_spheres = 0, n_nodes = 0;
@@ -192,7 +192,7 @@ void rrt_destroy(rrt_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (hipStream_t ss : c->side_stream) if (ss) (void)hipStreamSynchronize(ss);
-    for (DevBuf *b : {&c->nodes, &c->small_nodes, &c->top_nodes, &c->wide, &c->wide_top, &c->sph, &c->motion, &c->motion_dt, &c->sph_info, &c->prim_att,
+    for (DevBuf *b : {&c->nodes, &c->small_nodes, &c->top_nodes, &c->wide, &c->sph, &c->motion, &c->motion_dt, &c->sph_info, &c->prim_att,
                       &c->tmp_rgb, &c->tmp_acc, &c->q_org, &c->q_dir, &c->q_time, &c->q_t, &c->q_obj, &c->tile_map})
         b->release();
     for (DevBuf &b : c->ws) b.release();
@@ -248,7 +248,6 @@ int upload_scene_impl(rrt_ctx *c, const rrt_sphere_soa *sp, const rrt_material_s
     HIP_TRY(up(c->small_nodes, L.small_nodes.data(), L.small_nodes.size() * 4));
     HIP_TRY(up(c->top_nodes, L.top_nodes.data(), L.top_nodes.size() * 4));
     HIP_TRY(up(c->wide, L.wide.data(), L.wide.size() * 4));
-    HIP_TRY(up(c->wide_top, L.wide_top.data(), L.wide_top.size() * 4));
     HIP_TRY(up(c->sph, L.sph.data(), L.sph.size() * sizeof(Float4)));
     HIP_TRY(up(c->motion, L.motion.data(), L.motion.size() * sizeof(Float4)));
     HIP_TRY(up(c->motion_dt, L.motion_dt.data(), L.motion_dt.size() * 4));
@@ -275,7 +274,7 @@ int upload_scene_impl(rrt_ctx *c, const rrt_sphere_soa *sp, const rrt_material_s
     c->sd.top_nodes = L.top_nodes.empty() ? nullptr : c->top_nodes.as<uint4>();
     c->sd.n_top = (uint32_t)(L.top_nodes.size() / kNodeWords);
     c->sd.wide = L.wide.empty() ? nullptr : c->wide.as<uint4>();
-    c->sd.wide_top = L.wide.empty() ? nullptr : c->wide_top.as<uint4>();
+    c->sd.wide_root = L.wide_root;
     for (int k = 0; k < 6; k++) c->sd.root_box[k] = L.root_box[k];
     c->moving = (L.flags & kSceneHasMoving) != 0;
     c->n_spheres = L.n_spheres;

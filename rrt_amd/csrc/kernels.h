@@ -42,9 +42,11 @@ struct SceneDev {
     // copy of the top levels of the tree for scenes without a compact copy (references with kRefTopBit index it), or null
     const uint4 *top_nodes;
     uint32_t n_top;
-    // records of the two-children walk (scene_layout.h: SceneLayout::wide), indexed like `nodes` and like `top_nodes`; null
-    // when the scene has none (it fits in LDS, or its tree is deeper than the walk's stack)
-    const uint4 *wide, *wide_top;
+    // records of the two-children walk (scene_layout.h: SceneLayout::wide: the top-of-tree copy's first, inner nodes named
+    // by record index) and the root named the same way; null when the scene has none (it fits in LDS, or its tree is deeper
+    // than the walk's stack)
+    const uint4 *wide;
+    uint32_t wide_root;
     float root_box[6];  // the root's box as (min, max) per axis
 };
 

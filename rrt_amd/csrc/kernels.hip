@@ -509,7 +509,7 @@ struct WideStore {
     uint32_t n_top_lds;
     LdsStackPtr stack0;  // entry 0 of this lane's stack in LDS
     DEV WideStore(const SceneDev &s, LdsNodePtr top_copy, uint32_t n_top_copy, LdsStackPtr lane_stack) : S(s), top(top_copy), n_top_lds(n_top_copy), stack0(lane_stack) {}
-    DEV bool in_top_copy(uint32_t ref) const { return (ref & kRefTopBit) != 0u && (ref & kRefIndexMask) < n_top_lds; }
+    DEV bool in_top_copy(uint32_t ref) const { return ref < n_top_lds; }  // an inner node's reference is its record's index, and the first records are the copy
     DEV uint32_t end() const { return kRefEnd; }
     DEV bool uniform_times() const { return MOVING && (S.flags & kSceneUniformTimes); }
     DEV void prepare(RayCtx &) const {}
@@ -549,11 +549,11 @@ struct WideStore {
     DEV uint32_t start(RayCtx &r, WideStack &k, uint32_t &n_inner) const {
         k.clear();
         k.l = stack0;
-        if (S.root_ref & kRefLeafBit) return S.root_ref;
+        if (S.wide_root & kRefLeafBit) return S.wide_root;
         float t0, f;
         box_test(f2u(S.root_box[0]), f2u(S.root_box[1]), f2u(S.root_box[2]), f2u(S.root_box[3]), f2u(S.root_box[4]), f2u(S.root_box[5]), r, t0, f);
         if (COUNT) n_inner++;
-        return t0 <= fminf(f, r.tmax) ? S.root_ref : kRefEnd;
+        return t0 <= fminf(f, r.tmax) ? S.wide_root : kRefEnd;
     }
 };
 
@@ -563,10 +563,10 @@ struct WideStore {
 // scene.  It saves instructions, but each such leaf then costs a dependent fetch of its own.)
 template <bool MOVING, bool COUNT>
 DEV uint32_t visit_inner(const WideStore<MOVING, COUNT> &st, uint32_t cur, RayCtx &r, WideStack &k, bool quick, uint32_t &n_inner, uint32_t &n_leaf) {
-    const uint32_t idx = cur & kRefIndexMask;
+    const uint32_t idx = cur;
     uint4 q0, q1, q2, q3;
     if (st.in_top_copy(cur)) { q0 = load4(st.top, idx * 4u); q1 = load4(st.top, idx * 4u + 1u); q2 = load4(st.top, idx * 4u + 2u); q3 = load4(st.top, idx * 4u + 3u); }
-    else { const uint4 *src = ((cur & kRefTopBit) ? st.S.wide_top : st.S.wide) + (size_t)idx * 4u; q0 = src[0]; q1 = src[1]; q2 = src[2]; q3 = src[3]; }
+    else { const uint4 *src = st.S.wide + (size_t)idx * 4u; q0 = src[0]; q1 = src[1]; q2 = src[2]; q3 = src[3]; }
     const uint32_t left = q3.x, right = q3.y & kRefMask;
     const uint32_t axis = (q3.y >> RRT_NODE_AXIS_SHIFT) & 3u;
     const bool right_first = ((r.oct >> axis) & 1u) != 0u;  // acceleration.rs:253-267
@@ -907,7 +907,7 @@ __global__ __launch_bounds__(kLdsBlockThreads, 8) void k_extend_wide(SceneDev S,
     if (threadIdx.x < 2) pool[threadIdx.x] = 0u;
     const uint32_t n_top_lds = min(S.n_top, kWideTopLds);
     uint4 *top_copy = lds4 + kWideLdsEntries * kLdsBlockThreads / 2u;  // behind the stacks (8 bytes per entry)
-    for (uint32_t i = threadIdx.x; i < n_top_lds * 4u; i += kLdsBlockThreads) top_copy[i] = S.wide_top[i];
+    for (uint32_t i = threadIdx.x; i < n_top_lds * 4u; i += kLdsBlockThreads) top_copy[i] = S.wide[i];
     __syncthreads();
     if (lane == 0 && own_count) atomicAdd(&pool[1], own_count);
     __syncthreads();

@@ -285,31 +285,39 @@ void make_top_tree(SceneLayout &L) {
 }
 
 void make_wide_nodes(SceneLayout &L) {
-    L.wide.clear(); L.wide_top.clear();
+    L.wide.clear();
     if (L.top_nodes.empty() || L.root_ref == kRefEnd || L.max_leaf_depth >= kWideStackDepth) return;
     auto node_words = [&](uint32_t ref) -> const uint32_t * {
         const size_t idx = ref & kRefIndexMask;
         return (ref & kRefTopBit) ? &L.top_nodes[idx * kNodeWords] : &L.nodes[idx * kNodeWords];
     };
+    // One array: the records of the nodes of the top-of-tree copy first (in its order), then one per node of the node array.
+    // Inside the records an inner child is named by its record's index in that array (the walk's own reference to an inner
+    // node: a shift away from the record's address, and `index < n` says whether the record is among the first n, which the
+    // walk keeps in LDS); a leaf child keeps its node reference.
+    const size_t n_top = L.top_nodes.size() / kNodeWords;
+    auto wide_ref = [&](uint32_t ref) -> uint32_t {
+        if (ref & kRefLeafBit) return ref;
+        return (ref & kRefTopBit) ? (ref & kRefIndexMask) : static_cast<uint32_t>(n_top) + (ref & kRefIndexMask);
+    };
     auto fill = [&](const uint32_t *w, uint32_t *rec) {  // w: an inner node's words, references already final
         const uint32_t left = w[7], right = w[6] & kRefMask;
         const uint32_t *lw = node_words(left), *rw = node_words(right);
         for (int k = 0; k < 6; k++) { rec[k] = lw[k]; rec[6 + k] = rw[k]; }
-        rec[12] = left; rec[13] = w[6];
+        rec[12] = wide_ref(left); rec[13] = wide_ref(right) | (w[6] & ~kRefMask);  // word 13 keeps the split axis
         rec[14] = rec[15] = 0u;
     };
-    L.wide.assign(static_cast<size_t>(L.n_nodes) * kNodeWords, 0u);
+    L.wide.assign((n_top + static_cast<size_t>(L.n_nodes)) * kNodeWords, 0u);
     parallel_ranges(L.n_nodes, [&](size_t begin, size_t end) {
         for (size_t i = begin; i < end; i++)
-            if (L.node_kind[i] == 1) fill(&L.nodes[i * kNodeWords], &L.wide[i * kNodeWords]);
+            if (L.node_kind[i] == 1) fill(&L.nodes[i * kNodeWords], &L.wide[(n_top + i) * kNodeWords]);
     });
-    const size_t n_top = L.top_nodes.size() / kNodeWords;
-    L.wide_top.assign(n_top * kNodeWords, 0u);
     for (size_t k = 0; k < n_top; k++) {
         const uint32_t *w = &L.top_nodes[k * kNodeWords];
         // an inner node's child references are never zero (node 0 is the root, nobody's child); a leaf's words 6 and 7 are
-        if (w[6] != 0u || w[7] != 0u) fill(w, &L.wide_top[k * kNodeWords]);
+        if (w[6] != 0u || w[7] != 0u) fill(w, &L.wide[k * kNodeWords]);
     }
+    L.wide_root = wide_ref(L.root_ref);
     const uint32_t *rw = node_words(L.root_ref);
     for (int k = 0; k < 6; k++) { uint32_t u = rw[k]; std::memcpy(&L.root_box[k], &u, 4); }
     L.flags |= kSceneWideRecords;

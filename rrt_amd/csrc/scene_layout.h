@@ -88,11 +88,14 @@ struct SceneLayout {
     std::vector<uint32_t> top_nodes;
 
     // Records of the two-children walk of big scenes (filled by make_wide_nodes, after make_top_tree; empty if the tree is
-    // deeper than the walk's stack): one 64-byte record per inner node, indexed like `nodes` (`wide`) and like `top_nodes`
-    // (`wide_top`).  Words [0..5] describe the left child and [6..11] the right child: an inner child's box as (min, max)
-    // per axis, a leaf child's sphere as in a leaf node (centre at time0, radius^2, sphere word, moving flag);
-    // [12] left reference, [13] right reference | axis << 29.  `root_box`: the root's own box (no record holds it).
-    std::vector<uint32_t> wide, wide_top;
+    // deeper than the walk's stack): one 64-byte record per inner node, in one array: first the records of the nodes of the
+    // top-of-tree copy, in its order, then one per node of `nodes`.  Words [0..5] describe the left child and [6..11] the
+    // right child: an inner child's box as (min, max) per axis, a leaf child's sphere as in a leaf node (centre at time0,
+    // radius^2, sphere word, moving flag); [12] left child, [13] right child | axis << 29, where an inner child is named by
+    // the index of its record in this array and a leaf child by its node reference.  `wide_root`: the root, named the same
+    // way.  `root_box`: the root's own box (no record holds it).
+    std::vector<uint32_t> wide;
+    uint32_t wide_root = kRefEnd;
     float root_box[6] = {0, 0, 0, 0, 0, 0};
 
     std::vector<Float4> sph;        // {centre at time0, radius}
@@ -110,7 +113,7 @@ struct SceneLayout {
 // every reference to one of them, in `nodes`, `top_nodes` and `root_ref`, as kRefTopBit | index in `top_nodes`.
 void make_top_tree(SceneLayout &layout);
 
-// Builds `wide`, `wide_top` and `root_box` from `nodes` / `top_nodes` (call after make_top_tree).
+// Builds `wide`, `wide_root` and `root_box` from `nodes` / `top_nodes` (call after make_top_tree).
 constexpr uint32_t kWideStackDepth = 64;  // deferred children a ray can hold: one per level of the tree at most
 void make_wide_nodes(SceneLayout &layout);
 
