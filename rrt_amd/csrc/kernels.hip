@@ -38,18 +38,18 @@ DEV V3 scale(float s, V3 a) { return mk(s * a.x, s * a.y, s * a.z); }
 DEV V3 neg(V3 a) { return mk(-a.x, -a.y, -a.z); }
 // ultraviolet Vec4::dot with both w lanes zero: x.mul_add(ox, y.mul_add(oy, z.mul_add(oz, 0)))
 DEV float dot3(V3 a, V3 b) { return __builtin_fmaf(a.x, b.x, __builtin_fmaf(a.y, b.y, __builtin_fmaf(a.z, b.z, 0.0f))); }
-// Correctly rounded square root.  It is the sequence the compiler emits
-// for sqrtf (hardware estimate, then the neighbours one ulp down and up are tried against x with exact fma
-// residuals), without the rescaling of inputs below 2^-96 that the estimate cannot take: if any lane of the wave
-// has such an input the whole wave takes sqrtf.  Zero and +inf come out of the short sequence unchanged.
+// Correctly rounded square root in 5 instructions instead of the 20 of sqrtf: the hardware's reciprocal-root estimate y,
+// the root estimate s = x y, and one Newton step on s with the exact fma residual x - s s and the slope y / 2.  Checked
+// against sqrtf on every non-negative input (tools/micro/sqrt_exact.hip): the result is the same bit for bit for every x
+// from 2^-102 up to the largest finite value; below that (zero and denormals included) and for +inf the result is NaN or
+// a number below 2^-51.  Both show in the result: if any lane of the wave has one, the whole wave takes sqrtf.
+DEV bool sqrt_suspect(float s) { return !(s >= 0x1p-48f); }
 DEV float sqrt_rn(float x) {
-    if (__builtin_expect(__ballot(x < 0x1p-96f) != 0ull, 0)) return sqrtf(x);
-    const float s = __builtin_amdgcn_sqrtf(x);
-    const float dn = u2f(f2u(s) - 1u), up = u2f(f2u(s) + 1u);
-    const float r_dn = __builtin_fmaf(-dn, s, x), r_up = __builtin_fmaf(-up, s, x);
-    float r = (r_dn <= 0.0f) ? dn : s;
-    r = (r_up > 0.0f) ? up : r;
-    return r;
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float s0 = x * y;
+    float s = __builtin_fmaf(__builtin_fmaf(-s0, s0, x), 0.5f * y, s0);
+    if (__builtin_expect(__ballot(sqrt_suspect(s)) != 0ull, 0)) s = sqrtf(x);
+    return s;
 }
 
 // Correctly rounded 1 / x in 3 instructions instead of the 11 of an IEEE division: the hardware estimate and one

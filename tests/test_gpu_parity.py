@@ -403,6 +403,44 @@ def test_rejection_work_list_extremes(gpu_ctx, kind):
     assert gpu[2]["depth_cut"] == ref[2]["depth_cut"] and ref[2]["depth_cut"] > 0   # (glass: a few paths are caught inside the small sphere)
 
 
+@pytest.mark.parametrize("scale", [1e-15, 2e-8, 1.0, 1e7])
+def test_scaled_scenes_reach_the_slow_paths_of_the_short_sequences(gpu_ctx, scale):
+    """Sphere::hit (sphere.rs:68-85) takes a square root of the discriminant and divides by |d|^2; the kernels do both with
+    short sequences that are exact over a stated range and hand the rest to the IEEE routines, wave by wave.  The same scene at
+    four scales: at 1e-15 every discriminant of a camera ray is far below 2^-96 (all waves on the IEEE routines), at 2e-8 they
+    straddle it (mixed waves), at 1 and 1e7 none is."""
+    rng = np.random.default_rng(5)
+    n = 40
+    sp = np.zeros((n, 9), np.float32)
+    c = rng.uniform(-3.0, 3.0, (n, 3)) * (1.0, 0.15, 1.0)
+    c[0] = (0.0, -200.3, 0.0)
+    rad = rng.uniform(0.1, 0.45, n)
+    rad[0] = 200.0
+    sp[:, 0:3] = sp[:, 3:6] = c * scale
+    sp[:, 7] = 1.0
+    sp[:, 8] = rad * scale
+    kinds = rng.integers(0, 3, n)
+    kinds[0] = 0
+    mt = np.zeros((n, 6), np.float32)
+    mt[:, 0] = kinds
+    mt[:, 1:4] = rng.uniform(0.3, 0.95, (n, 3))
+    mt[:, 4] = np.where(kinds == 1, rng.uniform(0.0, 0.4, n), 0.0)
+    mt[:, 5] = np.where(kinds == 2, 1.5, 0.0)
+    mid = np.arange(n, dtype=np.uint32)
+    eye = np.array((4.0, 1.2, 5.0)) * scale
+    cam = rrt_amd.camera_from(tuple(eye), (0.0, 0.0, 0.0), (0, 1, 0), 40.0, 1.5, 0.05 * scale, 6.0 * scale, 0.0, 0.0)
+    osc = OracleScene.from_arrays(sp, mid, mt, np.zeros((0, 8), np.uint32), cam.as_array())
+    osc.build_bvh(0)
+    _, _, _, nd, _ = scene_arrays_from_oracle(osc)
+    gpu_ctx.upload_scene(sp, mid, mt, nd)
+    gpu_ctx.set_camera(cam)
+    nx, ny, ns = 96, 64, 6
+    ref = osc.render(nx, ny, ns, seed=17, threads=8)
+    gpu = gpu_ctx.render(rrt_amd.Context.params(nx, ny, ns, seed=17, count_work=True))
+    assert_same_image(gpu, ref)
+    assert ref[2]["hits_lambertian"] + ref[2]["hits_metal"] + ref[2]["hits_dielectric"] > nx * ny * ns // 2, ref[2]
+
+
 @pytest.mark.parametrize("max_depth", [50, 300])   # 300: beyond what the narrow per-slot state holds, so the wide layout runs on a small scene
 def test_long_paths_between_two_walls(gpu_ctx, max_depth):
     """A narrow gap between two huge diffuse/metal spheres: paths scatter dozens of times before they see the sky, so the
