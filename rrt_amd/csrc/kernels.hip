@@ -256,8 +256,8 @@ DEV bool quick_div_ok(const RayCtx &r) {
     return r.a >= 0x1p-30f && r.a <= 0x1p30f && fmaxf(fmaxf(fabsf(r.ox.x), fabsf(r.oy.x)), fabsf(r.oz.x)) <= 0x1p30f &&
            (!MOVING || (r.f_ray >= 0.0f && r.f_ray <= 1.0f));
 }
-DEV float div_by_a(float n, const RayCtx &r, bool quick) {
-    if (!quick) return n / r.a;
+DEV float div_by_a(float n, const RayCtx &r, uint32_t quick) {  // quick: 0 or 1, the same in every lane
+    if (quick == 0u) return n / r.a;
     const float q0 = n * r.ra;
     return __builtin_fmaf(__builtin_fmaf(-r.a, q0, n), r.ra, q0);
 }
@@ -408,7 +408,7 @@ DEV void slab_interval(f32x2 bx, f32x2 by, f32x2 bz, const RayCtx &r, float &t0,
 }
 
 template <bool MOVING, class TopPtr>
-DEV uint32_t visit_inner(const HbmStore<MOVING, TopPtr> &st, uint32_t cur, RayCtx &r, NoStack &, bool, uint32_t &, uint32_t &) {
+DEV uint32_t visit_inner(const HbmStore<MOVING, TopPtr> &st, uint32_t cur, RayCtx &r, NoStack &, uint32_t, uint32_t &, uint32_t &) {
     f32x2 bx, by, bz;
     uint32_t near_ref, exit_ref;
     st.inner(cur, r, bx, by, bz, near_ref, exit_ref);
@@ -418,7 +418,7 @@ DEV uint32_t visit_inner(const HbmStore<MOVING, TopPtr> &st, uint32_t cur, RayCt
 }
 
 template <bool MOVING>
-DEV uint32_t visit_inner(const LdsStore<MOVING> &st, uint32_t cur, RayCtx &r, NoStack &, bool, uint32_t &, uint32_t &) {
+DEV uint32_t visit_inner(const LdsStore<MOVING> &st, uint32_t cur, RayCtx &r, NoStack &, uint32_t, uint32_t &, uint32_t &) {
     f32x2 bx, by, bz;
     uint32_t links;
     st.inner(cur, r, bx, by, bz, links);
@@ -434,7 +434,9 @@ DEV uint32_t visit_inner(const LdsStore<MOVING> &st, uint32_t cur, RayCtx &r, No
 // Sphere::hit (sphere.rs:68-85); the Hit record itself is rebuilt in shade, for the final hit only.  (Deferring the
 // square root and divisions until many lanes need them was tried: lanes that wait for roots cost the descent passes as
 // many idle lanes as the batched root passes save.)
-DEV void sphere_test(V3 c, float rr, uint32_t handle, RayCtx &r, bool quick) {  // quick: wave-uniform, every ray of the wave passes quick_div_ok
+// quick: 0 or 1, the same in every lane (a number and not a bool: as a bool the compiler keeps it as a lane mask and spends two
+// vector instructions per use on turning it over): every ray of the wave passes quick_div_ok
+DEV void sphere_test(V3 c, float rr, uint32_t handle, RayCtx &r, uint32_t quick) {
     const V3 oc = sub(origin(r), c);
     const float half_b = dot3(oc, r.d);
     const float cc = dot3(oc, oc) - rr;
@@ -452,7 +454,7 @@ DEV void sphere_test(V3 c, float rr, uint32_t handle, RayCtx &r, bool quick) {  
 }
 
 template <class Store>
-DEV uint32_t visit_leaf(const Store &st, uint32_t cur, RayCtx &r, NoStack &, bool quick, uint32_t &, uint32_t &) {
+DEV uint32_t visit_leaf(const Store &st, uint32_t cur, RayCtx &r, NoStack &, uint32_t quick, uint32_t &, uint32_t &) {
     V3 c;
     float rr;
     uint32_t handle, exit_ref;
@@ -524,7 +526,7 @@ struct WideStore {
         slab_entry_exit(bx, by, bz, r, t0, f);
     }
     // a leaf's six words: centre at time0, radius^2, sphere word, moving flag
-    DEV void leaf_test(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t w4, uint32_t w5, RayCtx &r, bool quick) const {
+    DEV void leaf_test(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t w4, uint32_t w5, RayCtx &r, uint32_t quick) const {
         V3 c = mk(u2f(w0), u2f(w1), u2f(w2));
         if (MOVING && (w5 & 1u)) {  // center_at (sphere.rs:61-64)
             const uint32_t prim = w4 & kLeafPrimMask;
@@ -562,7 +564,7 @@ struct WideStore {
 // wave's next sphere pass instead, as the walks along exit links do, was slower: 824 ms against 760 on the 1 M-sphere
 // scene.  It saves instructions, but each such leaf then costs a dependent fetch of its own.)
 template <bool MOVING, bool COUNT>
-DEV uint32_t visit_inner(const WideStore<MOVING, COUNT> &st, uint32_t cur, RayCtx &r, WideStack &k, bool quick, uint32_t &n_inner, uint32_t &n_leaf) {
+DEV uint32_t visit_inner(const WideStore<MOVING, COUNT> &st, uint32_t cur, RayCtx &r, WideStack &k, uint32_t quick, uint32_t &n_inner, uint32_t &n_leaf) {
     const uint32_t idx = cur;
     uint4 q0, q1, q2, q3;
     if (st.in_top_copy(cur)) { q0 = load4(st.top, idx * 4u); q1 = load4(st.top, idx * 4u + 1u); q2 = load4(st.top, idx * 4u + 2u); q3 = load4(st.top, idx * 4u + 3u); }
@@ -605,7 +607,7 @@ DEV uint32_t visit_inner(const WideStore<MOVING, COUNT> &st, uint32_t cur, RayCt
 
 // a leaf that waited on the stack (or the root of a one-sphere scene): its words come from its own node
 template <bool MOVING, bool COUNT>
-DEV uint32_t visit_leaf(const WideStore<MOVING, COUNT> &st, uint32_t cur, RayCtx &r, WideStack &k, bool quick, uint32_t &n_inner, uint32_t &n_leaf) {
+DEV uint32_t visit_leaf(const WideStore<MOVING, COUNT> &st, uint32_t cur, RayCtx &r, WideStack &k, uint32_t quick, uint32_t &n_inner, uint32_t &n_leaf) {
     const uint32_t idx = cur & kRefIndexMask;
     const uint4 *src = (cur & kRefTopBit) ? st.S.top_nodes : st.S.nodes;
     const uint4 a = src[idx * 4u], b = src[idx * 4u + 1u];
@@ -664,7 +666,7 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
     ray_load(r, make_float4(0, 0, 0, 0), make_float4(1, 1, 1, 0), make_float4(1, 1, 1, 3), 0.001f, __FLT_MAX__, S, false);
     uint32_t cur = kEnd;
     const bool may_quick = (S.flags & kSceneBounded) != 0u && P.t_min >= 0x1p-40f;
-    bool quick = false;  // wave-uniform: every ray the wave holds may be divided the short way (div_by_a)
+    uint32_t quick = 0u;  // wave-uniform, 0 or 1: every ray the wave holds may be divided the short way (div_by_a)
     for (;;) {
         const bool idle = cur == kEnd;
         const uint64_t idle_m = __ballot(idle);
@@ -702,7 +704,7 @@ DEV void extend_wave(const Store &st, const SceneDev &S, const PathState &P, uin
                 cur = st.start(r, stk, n_inner);
                 has = true;
             }
-            quick = may_quick && __ballot(has && !quick_div_ok<MOVING>(r)) == 0ull;
+            quick = (may_quick && __ballot(has && !quick_div_ok<MOVING>(r)) == 0ull) ? 1u : 0u;
             n_taken += (uint32_t)__popcll(__ballot(take));
             head += min(n_idle, count - head);  // pooled: reaches `count` once a grab runs past the end of the pool
             if (__ballot(has) == 0ull) break;
