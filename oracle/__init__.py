@@ -222,6 +222,15 @@ class OracleScene:
                                           acc.ctypes.data, rgb.ctypes.data, C.byref(rays))
         return acc, rgb, rays.value
 
+    def trace_path_rays(self, nx, ny, seed, idx, k, max_depth=50, pow5_mode=0):
+        """The rays of one path, in order: [n, 7] f32 (origin, direction, time)."""
+        buf = np.zeros((max_depth + 2, 7), np.float32)
+        f = lib().orc_trace_path_rays
+        f.restype = C.c_uint64
+        f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_uint64]
+        n = f(self._h, nx, ny, seed, idx, k, max_depth, pow5_mode, buf.ctypes.data, buf.shape[0])
+        return buf[:n]
+
     def trace_path(self, nx, ny, seed, idx, k, max_depth=50, pow5_mode=0):
         out = np.zeros(3, np.float32)
         rays = C.c_uint64(0)

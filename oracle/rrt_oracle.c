@@ -566,9 +566,21 @@ static ray_t camera_gen_ray(const camera_t *c, float s, float t, xrng *g) { /* c
 /* ------------------------------------------------------------------------------------------ */
 /* Integrator (lib.rs:50-113)                                                                   */
 /* ------------------------------------------------------------------------------------------ */
+/* Debugging aid (orc_trace_path_rays): when set, every ray trace() is given is appended here, 7 floats each. */
+static __thread float *g_ray_log = NULL;
+static __thread uint64_t g_ray_log_cap = 0, g_ray_log_n = 0;
+
 static v4 trace(const scene_t *sc, const ray_t *r, int depth, xrng *g, ctrs_t *C, const opts_t *O) { /* lib.rs:50-71 */
     hit_t h;
     C->rays++;
+    if (g_ray_log) {
+        if (g_ray_log_n < g_ray_log_cap) {
+            float *o = g_ray_log + g_ray_log_n * 7;
+            o[0] = r->origin.x; o[1] = r->origin.y; o[2] = r->origin.z;
+            o[3] = r->direction.x; o[4] = r->direction.y; o[5] = r->direction.z; o[6] = r->time;
+        }
+        g_ray_log_n++;
+    }
     if (bvh_hit(sc, r, 0.001f, FLT_MAX, &h, C)) {
         if (depth >= O->max_depth) { C->depth_cut++; return v4_splat(0.0f); }
         scattered_t s;
@@ -1007,6 +1019,18 @@ ORC_API void orc_render_pixels_shard(const orc_scene *s, uint32_t nx, uint32_t n
         pixel_finish(c, n_local ? n_local : 1, rgb + (size_t)i * 3, acc + (size_t)i * 3);
     }
     if (rays) *rays = C.rays;
+}
+
+/* The rays of one path in the order trace() meets them: (origin, direction, time) x up to `cap`; returns how many the path has. */
+ORC_API uint64_t orc_trace_path_rays(const orc_scene *s, uint32_t nx, uint32_t ny, uint64_t seed, uint32_t idx, uint32_t k,
+                                     int max_depth, int pow5_mode, float *rays7, uint64_t cap) {
+    opts_t O = {max_depth, pow5_mode};
+    ctrs_t C; memset(&C, 0, sizeof C);
+    xrng g; rng_seed_from_u64(&g, sample_stream_seed(seed, idx, k));
+    g_ray_log = rays7; g_ray_log_cap = cap; g_ray_log_n = 0;
+    (void)pixel_sample(&s->sc, &s->cam, nx, ny, idx, &g, &C, &O);
+    g_ray_log = NULL;
+    return g_ray_log_n;
 }
 
 /* One path, for debugging and fine-grained parity: radiance of (pixel idx, sample k) in per-sample mode. */

@@ -473,7 +473,7 @@ DEV uint32_t visit_leaf(const Store &st, uint32_t cur, RayCtx &r, NoStack &, uin
 // miss or a leaf, in which case the far child is next anyway and is dealt with in the same visit.  The reference tests a
 // waiting child's box when it pops it, against the closest hit so far; the entry distance t0 and the scaled exit
 // distance do not depend on that, so the box is worked out when the record is at hand, the child is dropped if it misses
-// even the current t_max (t_max only shrinks), and otherwise waits with its t0: popping it is `t0 <= t_max`.
+// even the current t_max (t_max only shrinks), and otherwise waits with its t0: popping it is `!(t0 > t_max)`.
 // Waiting children are kept by their position on the stack: the first kWideLdsEntries positions in LDS (entry k of the
 // workgroup's lane l at (k * 1024 + l) * 8, no bank conflicts), deeper ones in scratch memory.  Scratch goes through the
 // same address path as the record gathers, which is what bounds this walk (a first version with the whole stack in
@@ -543,7 +543,10 @@ struct WideStore {
             const uint2 e = k.pop();
             if (e.x & kRefLeafBit) return e.x;
             if (COUNT) n_inner++;
-            if (u2f(e.y) <= r.tmax) return e.x;
+            // Aabb::intersect's t0 <= min(exit, t_max) with t0 <= exit known since the push.  Spelled as "not beyond t_max": f32::min
+            // drops a NaN t_max (a ray with a zero direction accepts every sphere it tests at t = NaN, sphere.rs:74-81), and the
+            // box is then hit
+            if (!(u2f(e.y) > r.tmax)) return e.x;
         }
         return kRefEnd;
     }
