@@ -1043,3 +1043,44 @@ def test_zero_direction_ray_inside_a_path_of_a_big_scene(gpu_ctx):
         assert_same_image(gpu, ref)
         for k in ("rays", "hits_metal", "hits_lambertian", "absorbed", "depth_cut", "inner_visits", "leaf_tests"):
             assert gpu[2][k] == ref[2][k], (walk, k, gpu[2][k], ref[2][k])
+
+
+@pytest.mark.parametrize("scene", ["chap12", "book2chap2", "big"])
+def test_paths_without_a_direction(gpu_ctx, scene):
+    """A camera whose viewport has no extent, at the lens: every camera ray has direction (0, 0, 0).  Such a ray accepts every
+    sphere it is tested against at t = NaN (sphere.rs:74-81: a NaN root is neither below t_min nor beyond t_max), the hit point
+    is NaN, and what follows is a path of NaN rays, which pass every box (f32::max / f32::min drop the NaNs,
+    acceleration.rs:77-82) and go on from the last sphere in walk order until a metal sphere absorbs them or the depth limit
+    cuts them.  The reference meets such paths when refracted() returns no direction; here they are the whole image, from
+    several places in the scene, through the walk in LDS and both walks in HBM."""
+    if scene == "big":
+        osc = OracleScene.build(rrt_amd.SCENE_RANDOM_SPHERES, 16, 8, seed=2, half=29)
+    else:
+        osc = OracleScene.build(SCENES[scene], 16, 8, seed=0)
+    sp, mid, mt, nd, cam21 = scene_arrays_from_oracle(osc)
+    gpu_ctx.upload_scene(sp, mid, mt, nd)
+    kinds_met = set()
+    walks = ({}, {"exit_link_walk": True}) if scene == "big" else ({}, {"force_hbm_bvh": True})
+    for k, eye in enumerate([(0.3, 0.2, 0.4), (4.0, 1.0, 0.0), (-4.0, 0.9, 0.1), (0.0, 1.0, 0.0), (2.1, 0.2, -3.3), (-7.5, 0.21, 5.2), (0.0, -900.0, 0.0), (30.0, 40.0, 5.0)]):
+        cam = rrt_amd.Camera()
+        cam.lower_left_corner[:] = eye
+        cam.origin[:] = eye
+        cam.horizontal[:] = (0.0, 0.0, 0.0)
+        cam.vertical[:] = (0.0, 0.0, 0.0)
+        cam.u[:] = (1.0, 0.0, 0.0)
+        cam.v[:] = (0.0, 1.0, 0.0)
+        cam.lens_radius, cam.time_low, cam.time_scale = 0.0, 0.0, 1.0
+        osc.set_camera21(cam.as_array())
+        gpu_ctx.set_camera(cam)
+        ref = osc.render(16, 8, 3, seed=5 + k, max_depth=20, threads=4)
+        for walk in walks:
+            gpu = gpu_ctx.render(rrt_amd.Context.params(16, 8, 3, seed=5 + k, max_depth=20, count_work=True, **walk))
+            # a NaN sum (the sky seen along a NaN direction) is compared as NaN: the sign and payload of a NaN that an operation
+            # makes (0 * inf, 0 / 0) are the processor's choice, x86 makes it negative, the GPU positive; RGB8 is 0 either way
+            both_nan = np.isnan(gpu[1]) & np.isnan(ref[1])
+            assert np.array_equal(np.isnan(gpu[1]), np.isnan(ref[1]))
+            assert_same_image((gpu[0], np.where(both_nan, np.float32(0), gpu[1]), gpu[2]), (ref[0], np.where(both_nan, np.float32(0), ref[1]), ref[2]))
+            for key in ("rays", "hits_metal", "hits_lambertian", "hits_dielectric", "absorbed", "depth_cut", "sky_misses", "inner_visits", "leaf_tests"):
+                assert gpu[2][key] == ref[2][key], (eye, walk, key, gpu[2][key], ref[2][key])
+        kinds_met |= {key for key in ("hits_metal", "hits_lambertian", "hits_dielectric", "sky_misses") if ref[2][key]}
+    assert len(kinds_met) >= 2, kinds_met

@@ -41,12 +41,27 @@ while time.time() < t_end:
     sp, mid, mt, nd, cam21 = scene_arrays_from_oracle(osc)
     ctx.upload_scene(sp, mid, mt, nd)
     ctx.set_camera(rrt_amd.Camera.from_buffer_copy(cam21.tobytes()))
+    if rng.integers(0, 16) == 0:  # a viewport without extent at the lens: every camera ray has direction (0, 0, 0), and NaN rays follow
+        cam = rrt_amd.Camera()
+        eye = rng.uniform(-8.0, 8.0, 3) * (1.0, 0.15, 1.0) + (0.0, 0.6, 0.0)
+        cam.lower_left_corner[:] = eye
+        cam.origin[:] = eye
+        cam.u[:] = (1.0, 0.0, 0.0)
+        cam.v[:] = (0.0, 1.0, 0.0)
+        cam.time_scale = 1.0
+        osc.set_camera21(cam.as_array())
+        ctx.set_camera(cam)
     rgb_o, acc_o, ct = osc.render(nx, ny, ns, seed=seed, max_depth=depth, threads=8)
     p = rrt_amd.Context.params(nx, ny, ns, seed=seed, max_depth=depth, path_slots=slots, batch_samples=batch, force_hbm_bvh=force_hbm,
                                count_work=bool(rng.integers(0, 2)))
     rgb, acc, st = ctx.render(p)
     tag = f"kind {kind} half {half} {nx}x{ny}x{ns} depth {depth} slots {slots} batch {batch} parts {parts} hbm {force_hbm} seed {seed}/{scene_seed} merge {os.environ['RRT_FINISH_MERGE']} delay {os.environ['RRT_FINISH_DELAY']} no_finish {os.environ.get('RRT_NO_FINISH', '0')}"
-    ok = np.array_equal(acc.view(np.uint32), acc_o.view(np.uint32)) and np.array_equal(rgb, rgb_o) and st["rays"] == ct["rays"]
+    # (a sum that is NaN on both sides counts as equal: the sign of a NaN that an operation makes is the processor's choice)
+    nan2 = np.isnan(acc) & np.isnan(acc_o)
+    if nan2.any(): print("note:", int(nan2.sum()), "NaN sums on both sides,", tag, flush=True)
+    ok = np.array_equal(np.where(nan2, 0, acc.view(np.uint32)), np.where(nan2, 0, acc_o.view(np.uint32))) and np.array_equal(rgb, rgb_o) and st["rays"] == ct["rays"]
+    if ok and p.count_work:
+        ok = all(st[k] == ct[k] for k in ("inner_visits", "leaf_tests", "hits_lambertian", "hits_metal", "hits_dielectric", "sky_misses", "depth_cut", "absorbed"))
     if not ok:
         print("MISMATCH", tag, flush=True)
         sys.exit(1)
