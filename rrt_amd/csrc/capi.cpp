@@ -774,7 +774,9 @@ int rrt_intersect(rrt_ctx *c, uint32_t n, const float *org, const float *dir, co
     ps.t_min = t_min; ps.t_max = t_max;
     ps.layout = c->moving ? kLayoutTimed : 0u;
     launch_intersect_setup(s, ps, n, c->q_org.as<float>(), c->q_dir.as<float>(), time ? c->q_time.as<float>() : nullptr);
-    launch_extend(s, c->sd, ps, c->moving, false, 32u, 16u, c->ws[WS_WAVE_STATS].as<uint64_t>());
+    SceneDev sd = c->sd;
+    if (!(t_min > 0.0f)) sd.wide = nullptr;  // the two-children walk keeps a mark in the sign of entry distances, which are t_min or more: along the exit links otherwise
+    launch_extend(s, sd, ps, c->moving, false, 32u, 16u, c->ws[WS_WAVE_STATS].as<uint64_t>());
     launch_intersect_gather(s, ps, n, c->q_t.as<float>(), c->q_obj.as<uint32_t>());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_t, c->q_t.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));

@@ -473,7 +473,7 @@ DEV uint32_t visit_leaf(const Store &st, uint32_t cur, RayCtx &r, NoStack &, uin
 // miss or a leaf, in which case the far child is next anyway and is dealt with in the same visit.  The reference tests a
 // waiting child's box when it pops it, against the closest hit so far; the entry distance t0 and the scaled exit
 // distance do not depend on that, so the box is worked out when the record is at hand, the child is dropped if it misses
-// even the current t_max (t_max only shrinks), and otherwise waits with its t0: popping it is `!(t0 > t_max)`.
+// whatever t_max is (entry beyond exit), and otherwise waits with its t0: popping it compares t0 with the t_max of that moment.
 // Waiting children are kept by their position on the stack: the first kWideLdsEntries positions in LDS (entry k of the
 // workgroup's lane l at (k * 1024 + l) * 8, no bank conflicts), deeper ones in scratch memory.  Scratch goes through the
 // same address path as the record gathers, which is what bounds this walk (a first version with the whole stack in
@@ -543,10 +543,14 @@ struct WideStore {
             const uint2 e = k.pop();
             if (e.x & kRefLeafBit) return e.x;
             if (COUNT) n_inner++;
-            // Aabb::intersect's t0 <= min(exit, t_max) with t0 <= exit known since the push.  Spelled as "not beyond t_max": f32::min
-            // drops a NaN t_max (a ray with a zero direction accepts every sphere it tests at t = NaN, sphere.rs:74-81), and the
-            // box is then hit
-            if (!(u2f(e.y) > r.tmax)) return e.x;
+            // Aabb::intersect's t0 <= min(exit, t_max) (acceleration.rs:81-83), where f32::min drops a NaN operand.  t0 <= exit is
+            // known since the push if the exit is a number; what is left is t0 <= min(+inf, t_max): a NaN t_max (a ray without a
+            // direction accepts every sphere it tests at t = NaN, sphere.rs:74-81) leaves the exit, and the box is hit.  If the exit
+            // is NaN itself (a NaN ray, which is what follows such a hit) the minimum is t_max, NaN or not: t0 <= min(NaN, t_max).
+            // The entry's sign says which: t0 is t_min or more, and this walk runs with t_min > 0 only.
+            const float t0 = fabsf(u2f(e.y));  // (the sign says that the exit distance is NaN; t0 itself is t_min or more, and t_min > 0 here)
+            const float limit = u2f(0x7F800000u | (((uint32_t)((int32_t)e.y >> 31)) & 0x00400000u));
+            if (t0 <= fminf(limit, r.tmax)) return e.x;
         }
         return kRefEnd;
     }
@@ -591,8 +595,14 @@ DEV uint32_t visit_inner(const WideStore<MOVING, COUNT> &st, uint32_t cur, RayCt
     } else {
         if (COUNT) n_inner++;
         if (near_t0 <= fminf(near_f, r.tmax)) {  // Aabb::intersect's last step (acceleration.rs:82-83); the far child waits
-            if (far_leaf || far_t0 <= fminf(far_f, r.tmax)) k.push(make_uint2(far_ref, f2u(far_t0)));
-            else if (COUNT) n_inner++;  // the reference pops it later, and it misses then too: t_max only shrinks
+            // A waiting inner child is dropped here only if the ray leaves its box before it enters it, which nothing changes.  How
+            // its entry compares with t_max is looked at when it is popped, as the reference does: t_max can turn NaN in between
+            // (and grow again after that: a NaN t_max accepts any root above t_min).
+            if (far_leaf) k.push(make_uint2(far_ref, 0u));
+            else if (!(far_t0 > far_f)) {
+                k.push(make_uint2(far_ref, f2u(far_f != far_f ? -far_t0 : far_t0)));  // (a NaN exit distance takes a NaN ray)
+            }
+            else if (COUNT) n_inner++;  // the reference pops it later, and it misses then too
             return near_ref;
         }
     }

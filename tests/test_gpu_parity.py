@@ -115,12 +115,23 @@ def test_intersect_degenerate_rays_in_a_big_scene(gpu_ctx):
     d[13500:15000] = 0.0
     d[15000:15200] = np.float32(np.nan)
     org[15100:15200] = np.float32(np.nan)
+    # rays whose discriminants overflow for the spheres far from their origin (inf - inf: a NaN root, accepted) and not for those
+    # near it: t_max is a number first and NaN later in the walk, and boxes that lay beyond the number are hit again
+    d[15200:17000] *= np.float32(1e13)
+    org[16000:17000] *= np.float32(1e4)
+    d[17000:18000] *= np.float32(3e16)
     tm = rng.uniform(0, 1, n).astype(np.float32)
     t_o, obj_o, _, _, _ = osc.hit_rays(org, d, tm)
     t_g, obj_g = gpu_ctx.intersect(org, d, tm)
     assert np.array_equal(obj_g, obj_o)
     assert np.array_equal(bits(t_g), bits(t_o))
     assert (obj_o != 0xFFFFFFFF).sum() > 10000 and (obj_o > 0).sum() > 1000  # not only the ground
+    # a t_min that is not positive (the two-children walk is for t_min > 0: these go along the exit links) and a short t_max
+    for t_min, t_max in ((0.0, 3.4028234663852886e38), (-0.5, 40.0), (0.25, 15.0)):
+        t_o, obj_o, _, _, _ = osc.hit_rays(org, d, tm, t_min=t_min, t_max=t_max)
+        t_g, obj_g = gpu_ctx.intersect(org, d, tm, t_min=t_min, t_max=t_max)
+        assert np.array_equal(obj_g, obj_o), (t_min, t_max)
+        assert np.array_equal(bits(t_g), bits(t_o)), (t_min, t_max)
 
 
 # ---------------------------------------------------------------- whole path: tracescene
@@ -1084,3 +1095,47 @@ def test_paths_without_a_direction(gpu_ctx, scene):
                 assert gpu[2][key] == ref[2][key], (eye, walk, key, gpu[2][key], ref[2][key])
         kinds_met |= {key for key in ("hits_metal", "hits_lambertian", "hits_dielectric", "sky_misses") if ref[2][key]}
     assert len(kinds_met) >= 2, kinds_met
+
+
+@pytest.mark.parametrize("method", [0, 1])   # Middle: the giant sphere is a child of the root; EqualCount: it sits deep in the tree
+def test_t_max_turns_nan_in_the_middle_of_a_walk(gpu_ctx, method):
+    """A ground sphere of radius 3e19: |o - c|^2 and radius^2 both overflow, their difference is NaN, so is the root, and a NaN
+    root is accepted (sphere.rs:74-81).  Its box holds the whole scene, so a ray meets it at some point of its walk, before or
+    after spheres that gave it a finite t_max: from then on t_max is NaN, f32::min drops it from the box tests
+    (acceleration.rs:81), boxes that lay beyond the finite t_max are hit again, and every sphere tested after that with a root
+    above t_min replaces the hit.  Which sphere a ray ends on is a matter of exact walk order: rays and a small render, through
+    both HBM walks, work counters included."""
+    base = OracleScene.build(rrt_amd.SCENE_RANDOM_SPHERES, 48, 32, seed=4, half=29)
+    sp, mid, mt, _, cam21 = scene_arrays_from_oracle(base)
+    ground = int(np.argmax(sp[:, 8]))
+    assert sp[ground, 8] == 1000.0
+    sp = sp.copy()
+    sp[ground, 8] = np.float32(3e19)
+    sp[ground, 1] = sp[ground, 4] = np.float32(-3e19)
+    cam = rrt_amd.Camera.from_buffer_copy(cam21.tobytes())
+    osc = OracleScene.from_arrays(sp, mid, mt, np.zeros((0, 8), np.uint32), cam.as_array())
+    osc.build_bvh(method)
+    _, _, _, nd, _ = scene_arrays_from_oracle(osc)
+    gpu_ctx.upload_scene(sp, mid, mt, nd)
+    gpu_ctx.set_camera(cam)
+    rng = np.random.default_rng(9)
+    n = 20000
+    org = rng.uniform(-25, 25, (n, 3)).astype(np.float32)
+    org[:, 1] = rng.uniform(0.05, 2.0, n)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d[:, 1] *= np.float32(0.2)
+    tm = np.zeros(n, np.float32)
+    t_o, obj_o, _, _, _ = osc.hit_rays(org, d, tm)
+    t_g, obj_g = gpu_ctx.intersect(org, d, tm)
+    assert np.isnan(t_o).sum() > 1000 and (np.isfinite(t_o) & (t_o < 1e30)).sum() > 500   # both kinds of ending
+    assert np.array_equal(np.isnan(t_g), np.isnan(t_o))
+    assert np.array_equal(obj_g, obj_o)
+    assert np.array_equal(bits(t_g)[~np.isnan(t_o)], bits(t_o)[~np.isnan(t_o)])
+    ref = osc.render(48, 32, 4, seed=3, max_depth=12, threads=8)
+    for walk in ({}, {"exit_link_walk": True}):
+        gpu = gpu_ctx.render(rrt_amd.Context.params(48, 32, 4, seed=3, max_depth=12, count_work=True, **walk))
+        both_nan = np.isnan(gpu[1]) & np.isnan(ref[1])
+        assert np.array_equal(np.isnan(gpu[1]), np.isnan(ref[1]))
+        assert_same_image((gpu[0], np.where(both_nan, np.float32(0), gpu[1]), gpu[2]), (ref[0], np.where(both_nan, np.float32(0), ref[1]), ref[2]))
+        for key in ("rays", "hits_metal", "hits_lambertian", "hits_dielectric", "absorbed", "depth_cut", "sky_misses", "inner_visits", "leaf_tests"):
+            assert gpu[2][key] == ref[2][key], (walk, key, gpu[2][key], ref[2][key])
