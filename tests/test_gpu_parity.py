@@ -1097,15 +1097,16 @@ def test_paths_without_a_direction(gpu_ctx, scene):
     assert len(kinds_met) >= 2, kinds_met
 
 
+@pytest.mark.parametrize("scene", ["big", "chap12"])   # walked in HBM (two-children walk, walk along exit links) / in LDS (and in HBM when forced)
 @pytest.mark.parametrize("method", [0, 1])   # Middle: the giant sphere is a child of the root; EqualCount: it sits deep in the tree
-def test_t_max_turns_nan_in_the_middle_of_a_walk(gpu_ctx, method):
+def test_t_max_turns_nan_in_the_middle_of_a_walk(gpu_ctx, method, scene):
     """A ground sphere of radius 3e19: |o - c|^2 and radius^2 both overflow, their difference is NaN, so is the root, and a NaN
     root is accepted (sphere.rs:74-81).  Its box holds the whole scene, so a ray meets it at some point of its walk, before or
     after spheres that gave it a finite t_max: from then on t_max is NaN, f32::min drops it from the box tests
     (acceleration.rs:81), boxes that lay beyond the finite t_max are hit again, and every sphere tested after that with a root
     above t_min replaces the hit.  Which sphere a ray ends on is a matter of exact walk order: rays and a small render, through
     both HBM walks, work counters included."""
-    base = OracleScene.build(rrt_amd.SCENE_RANDOM_SPHERES, 48, 32, seed=4, half=29)
+    base = OracleScene.build(rrt_amd.SCENE_RANDOM_SPHERES, 48, 32, seed=4, half=29) if scene == "big" else OracleScene.build(rrt_amd.SCENE_CHAP12, 48, 32, seed=4)
     sp, mid, mt, _, cam21 = scene_arrays_from_oracle(base)
     ground = int(np.argmax(sp[:, 8]))
     assert sp[ground, 8] == 1000.0
@@ -1120,7 +1121,7 @@ def test_t_max_turns_nan_in_the_middle_of_a_walk(gpu_ctx, method):
     gpu_ctx.set_camera(cam)
     rng = np.random.default_rng(9)
     n = 20000
-    org = rng.uniform(-25, 25, (n, 3)).astype(np.float32)
+    org = rng.uniform(-25, 25, (n, 3)).astype(np.float32) * np.float32(1.0 if scene == "big" else 0.4)
     org[:, 1] = rng.uniform(0.05, 2.0, n)
     d = rng.normal(size=(n, 3)).astype(np.float32)
     d[:, 1] *= np.float32(0.2)
@@ -1132,7 +1133,7 @@ def test_t_max_turns_nan_in_the_middle_of_a_walk(gpu_ctx, method):
     assert np.array_equal(obj_g, obj_o)
     assert np.array_equal(bits(t_g)[~np.isnan(t_o)], bits(t_o)[~np.isnan(t_o)])
     ref = osc.render(48, 32, 4, seed=3, max_depth=12, threads=8)
-    for walk in ({}, {"exit_link_walk": True}):
+    for walk in (({}, {"exit_link_walk": True}) if scene == "big" else ({}, {"force_hbm_bvh": True})):
         gpu = gpu_ctx.render(rrt_amd.Context.params(48, 32, 4, seed=3, max_depth=12, count_work=True, **walk))
         both_nan = np.isnan(gpu[1]) & np.isnan(ref[1])
         assert np.array_equal(np.isnan(gpu[1]), np.isnan(ref[1]))

@@ -39,6 +39,16 @@ while time.time() < t_end:
     os.environ["RRT_FINISH_DELAY"] = str(int(rng.choice([0, 1, 3, 3, 7])))
     osc = OracleScene.build(kind, nx, ny, seed=scene_seed, half=half)
     sp, mid, mt, nd, cam21 = scene_arrays_from_oracle(osc)
+    if rng.integers(0, 12) == 0:
+        # the ground sphere blown up until |o - c|^2 - r^2 is inf - inf: a NaN root, which is accepted; t_max turns NaN in the middle of
+        # walks and can grow again after that.  Tree by either builder: with EqualCount the giant sits deep in the tree.
+        ground = int(np.argmax(sp[:, 8]))
+        sp = sp.copy()
+        sp[ground, 8] = np.float32(3e19)
+        sp[ground, 1] = sp[ground, 4] = np.float32(-3e19)
+        osc = OracleScene.from_arrays(sp, mid, mt, np.zeros((0, 8), np.uint32), rrt_amd.Camera.from_buffer_copy(cam21.tobytes()).as_array())
+        osc.build_bvh(int(rng.integers(0, 2)))
+        _, _, _, nd, _ = scene_arrays_from_oracle(osc)
     ctx.upload_scene(sp, mid, mt, nd)
     ctx.set_camera(rrt_amd.Camera.from_buffer_copy(cam21.tobytes()))
     if rng.integers(0, 16) == 0:  # a viewport without extent at the lens: every camera ray has direction (0, 0, 0), and NaN rays follow
