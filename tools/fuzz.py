@@ -39,6 +39,21 @@ while time.time() < t_end:
     os.environ["RRT_FINISH_DELAY"] = str(int(rng.choice([0, 1, 3, 3, 7])))
     osc = OracleScene.build(kind, nx, ny, seed=scene_seed, half=half)
     sp, mid, mt, nd, cam21 = scene_arrays_from_oracle(osc)
+    if rng.integers(0, 6) == 0:
+        # the whole scene and its camera scaled by a power of ten: the short reciprocal / division / square-root sequences of the kernels
+        # are exact over stated ranges and hand the rest to the IEEE routines, wave by wave
+        k = np.float32(10.0 ** int(rng.integers(-16, 10)))
+        sp = sp.copy()
+        sp[:, 0:6] *= k
+        sp[:, 8] *= k
+        cam = rrt_amd.Camera.from_buffer_copy(cam21.tobytes())
+        for field in (cam.lower_left_corner, cam.horizontal, cam.vertical, cam.origin):
+            for i in range(3): field[i] = np.float32(field[i]) * k
+        cam.lens_radius = np.float32(cam.lens_radius) * k
+        cam21 = cam.as_array()
+        osc = OracleScene.from_arrays(sp, mid, mt, np.zeros((0, 8), np.uint32), cam21)
+        osc.build_bvh(int(rng.integers(0, 2)))
+        _, _, _, nd, _ = scene_arrays_from_oracle(osc)
     if rng.integers(0, 12) == 0:
         # the ground sphere blown up until |o - c|^2 - r^2 is inf - inf: a NaN root, which is accepted; t_max turns NaN in the middle of
         # walks and can grow again after that.  Tree by either builder: with EqualCount the giant sits deep in the tree.
