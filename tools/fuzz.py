@@ -76,11 +76,20 @@ while time.time() < t_end:
         cam.time_scale = 1.0
         osc.set_camera21(cam.as_array())
         ctx.set_camera(cam)
-    rgb_o, acc_o, ct = osc.render(nx, ny, ns, seed=seed, max_depth=depth, threads=8)
+    shard = {}
+    world = rank = 0
+    if rng.integers(0, 8) == 0:  # one sample shard of a multi-GPU render: samples rank, rank + world, ... (lib.rs:96-103 split over ranks)
+        world = int(rng.integers(2, 6))
+        rank = int(rng.integers(0, world))
+        shard = dict(shard_mode=rrt_amd.SHARD_SAMPLE, rank=rank, world=world)
+        rgb_o, acc_o, ct = osc.render(nx, ny, ns, seed=seed, max_depth=depth, threads=8, k_begin=rank, k_step=world)
+    else:
+        rgb_o, acc_o, ct = osc.render(nx, ny, ns, seed=seed, max_depth=depth, threads=8)
     p = rrt_amd.Context.params(nx, ny, ns, seed=seed, max_depth=depth, path_slots=slots, batch_samples=batch, force_hbm_bvh=force_hbm,
-                               count_work=bool(rng.integers(0, 2)))
+                               count_work=bool(rng.integers(0, 2)), **shard)
     rgb, acc, st = ctx.render(p)
-    tag = f"kind {kind} half {half} {nx}x{ny}x{ns} depth {depth} slots {slots} batch {batch} parts {parts} hbm {force_hbm} seed {seed}/{scene_seed} merge {os.environ['RRT_FINISH_MERGE']} delay {os.environ['RRT_FINISH_DELAY']} no_finish {os.environ.get('RRT_NO_FINISH', '0')}"
+    if world: rgb_o = rgb  # (a shard's own RGB8 is not what the oracle's sharded render returns: its f32 sums and counters are compared)
+    tag = f"shard {rank}/{world} kind {kind} half {half} {nx}x{ny}x{ns} depth {depth} slots {slots} batch {batch} parts {parts} hbm {force_hbm} seed {seed}/{scene_seed} merge {os.environ['RRT_FINISH_MERGE']} delay {os.environ['RRT_FINISH_DELAY']} no_finish {os.environ.get('RRT_NO_FINISH', '0')}"
     # (a sum that is NaN on both sides counts as equal: the sign of a NaN that an operation makes is the processor's choice)
     nan2 = np.isnan(acc) & np.isnan(acc_o)
     if nan2.any(): print("note:", int(nan2.sum()), "NaN sums on both sides,", tag, flush=True)
