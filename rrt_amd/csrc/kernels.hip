@@ -380,6 +380,10 @@ DEV f32x2 slab_pair(f32x2 box, f32x2 oi) {
     return t;
 }
 
+// f32::min (the operand that is not NaN, if one is) of two values that arithmetic has made: v_min_f32 as it is.  fminf is the same
+// instruction behind two more that quiet a signalling NaN in either operand first, which an arithmetic result never is.
+DEV float min_quiet(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
 // The same without the last step: t0 as below, f the scaled exit distance before it is limited by t_max
 DEV void slab_entry_exit(f32x2 bx, f32x2 by, f32x2 bz, const RayCtx &r, float &t0, float &f) {
     const f32x2 tx = slab_pair(bx, r.ox), ty = slab_pair(by, r.oy), tz = slab_pair(bz, r.oz);
@@ -549,8 +553,8 @@ struct WideStore {
             // is NaN itself (a NaN ray, which is what follows such a hit) the minimum is t_max, NaN or not: t0 <= min(NaN, t_max).
             // The entry's sign says which: t0 is t_min or more, and this walk runs with t_min > 0 only.
             const float t0 = fabsf(u2f(e.y));  // (the sign says that the exit distance is NaN; t0 itself is t_min or more, and t_min > 0 here)
-            const float limit = u2f(0x7F800000u | (((uint32_t)((int32_t)e.y >> 31)) & 0x00400000u));
-            if (t0 <= fminf(limit, r.tmax)) return e.x;
+            const float limit = u2f(0x7F800000u | (uint32_t)((int32_t)e.y >> 31));  // +inf, or with the sign set all ones: a NaN
+            if (t0 <= min_quiet(limit, r.tmax)) return e.x;
         }
         return kRefEnd;
     }
@@ -562,7 +566,7 @@ struct WideStore {
         float t0, f;
         box_test(f2u(S.root_box[0]), f2u(S.root_box[1]), f2u(S.root_box[2]), f2u(S.root_box[3]), f2u(S.root_box[4]), f2u(S.root_box[5]), r, t0, f);
         if (COUNT) n_inner++;
-        return t0 <= fminf(f, r.tmax) ? S.wide_root : kRefEnd;
+        return t0 <= min_quiet(f, r.tmax) ? S.wide_root : kRefEnd;
     }
 };
 
@@ -594,7 +598,7 @@ DEV uint32_t visit_inner(const WideStore<MOVING, COUNT> &st, uint32_t cur, RayCt
                      right_first ? q2.z : q1.x, right_first ? q2.w : q1.y, r, quick);
     } else {
         if (COUNT) n_inner++;
-        if (near_t0 <= fminf(near_f, r.tmax)) {  // Aabb::intersect's last step (acceleration.rs:82-83); the far child waits
+        if (near_t0 <= min_quiet(near_f, r.tmax)) {  // Aabb::intersect's last step (acceleration.rs:82-83); the far child waits
             // A waiting inner child is dropped here only if the ray leaves its box before it enters it, which nothing changes.  How
             // its entry compares with t_max is looked at when it is popped, as the reference does: t_max can turn NaN in between
             // (and grow again after that: a NaN t_max accepts any root above t_min).
@@ -614,7 +618,7 @@ DEV uint32_t visit_inner(const WideStore<MOVING, COUNT> &st, uint32_t cur, RayCt
         return st.pop(r, k, n_inner);
     }
     if (COUNT) n_inner++;
-    if (far_t0 <= fminf(far_f, r.tmax)) return far_ref;
+    if (far_t0 <= min_quiet(far_f, r.tmax)) return far_ref;
     return st.pop(r, k, n_inner);
 }
 
