@@ -40,6 +40,18 @@ while time.time() < t_end:
     osc = OracleScene.build(kind, nx, ny, seed=scene_seed, half=half)
     sp, mid, mt, nd, cam21 = scene_arrays_from_oracle(osc)
     if rng.integers(0, 6) == 0:
+        # other materials than the scene builders make: any refraction index (below 1 too), fuzz beyond 1, albedo beyond 1, kinds reshuffled
+        mt = mt.copy()
+        n_m = mt.shape[0]
+        if rng.integers(0, 2): mt[:, 0] = rng.integers(0, 3, n_m)
+        mt[:, 1:4] = rng.uniform(0.0, 1.2, (n_m, 3))
+        mt[:, 4] = np.where(mt[:, 0] == 1, rng.uniform(0.0, 1.5, n_m), 0.0)
+        mt[:, 5] = np.where(mt[:, 0] == 2, rng.choice([1.5, 1.0, 0.5, 2.4, 1.33, 0.9999, 1.0001, 3.0], n_m) * rng.choice([1.0, 1.0, rng.uniform(0.9, 1.1)], n_m), 0.0)
+        mt = mt.astype(np.float32)
+        osc = OracleScene.from_arrays(sp, mid, mt, np.zeros((0, 8), np.uint32), cam21)
+        osc.build_bvh(0)
+        _, _, _, nd, _ = scene_arrays_from_oracle(osc)
+    if rng.integers(0, 6) == 0:
         # the whole scene and its camera scaled by a power of ten: the short reciprocal / division / square-root sequences of the kernels
         # are exact over stated ranges and hand the rest to the IEEE routines, wave by wave
         k = np.float32(10.0 ** int(rng.integers(-16, 10)))
