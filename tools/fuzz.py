@@ -39,6 +39,27 @@ while time.time() < t_end:
     os.environ["RRT_FINISH_DELAY"] = str(int(rng.choice([0, 1, 3, 3, 7])))
     osc = OracleScene.build(kind, nx, ny, seed=scene_seed, half=half)
     sp, mid, mt, nd, cam21 = scene_arrays_from_oracle(osc)
+    if rng.integers(0, 8) == 0:
+        # spheres set in motion with shutter intervals of their own (center_at divides by each sphere's interval, sphere.rs:61-64), a few
+        # of them with a negative radius or a -0.0 centre component
+        sp = sp.copy()
+        n_s = sp.shape[0]
+        mv = rng.integers(0, 3, n_s) == 0
+        mv[int(np.argmax(sp[:, 8]))] = False
+        sp[mv, 3:6] = sp[mv, 0:3] + rng.normal(0.0, 0.15, (int(mv.sum()), 3)).astype(np.float32)
+        if rng.integers(0, 2):
+            sp[:, 6] = rng.uniform(-0.5, 0.5, n_s).astype(np.float32)
+            sp[:, 7] = sp[:, 6] + rng.uniform(0.1, 2.0, n_s).astype(np.float32)
+        neg = rng.integers(0, 40, n_s) == 0
+        neg[int(np.argmax(sp[:, 8]))] = False
+        sp[neg, 8] = -sp[neg, 8]
+        sp[rng.integers(0, 50, n_s) == 0, 2] = np.float32(-0.0)
+        cam = rrt_amd.Camera.from_buffer_copy(cam21.tobytes())
+        if cam.time_scale == 0.0: cam.time_scale = 1.0  # (the still scenes' cameras keep the shutter closed at time 0)
+        cam21 = cam.as_array()
+        osc = OracleScene.from_arrays(sp, mid, mt, np.zeros((0, 8), np.uint32), cam21)
+        osc.build_bvh(int(rng.integers(0, 2)))
+        _, _, _, nd, _ = scene_arrays_from_oracle(osc)
     if rng.integers(0, 6) == 0:
         # other materials than the scene builders make: any refraction index (below 1 too), fuzz beyond 1, albedo beyond 1, kinds reshuffled
         mt = mt.copy()
