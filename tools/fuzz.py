@@ -7,6 +7,7 @@ import sys
 import time
 
 import numpy as np
+import torch  # before rrt_amd: the process must load torch's own HIP runtime first
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rrt_amd
@@ -18,7 +19,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 ctx = rrt_amd.Context(0)
 t_end = time.time() + budget
 big = len(sys.argv) > 3 and sys.argv[3] == "big"
-n_cases = 0
+n_cases = n_noalloc = 0
 while time.time() < t_end:
     kind = int(rng.integers(0, 4))
     half = int(rng.integers(3, 40)) if kind == 3 else 11
@@ -129,9 +130,27 @@ while time.time() < t_end:
     ok = np.array_equal(np.where(nan2, 0, acc.view(np.uint32)), np.where(nan2, 0, acc_o.view(np.uint32))) and np.array_equal(rgb, rgb_o) and st["rays"] == ct["rays"]
     if ok and p.count_work:
         ok = all(st[k] == ct[k] for k in ("inner_visits", "leaf_tests", "hits_lambertian", "hits_metal", "hits_dielectric", "sky_misses", "depth_cut", "absorbed"))
+    if ok and not big and rng.integers(0, 8) == 0:
+        # the same render through the entry point that allocates nothing (its own workspace, its own batch and pool sizes, big scenes
+        # along the exit links); sizes beyond its workspace are refused, which is not a mismatch
+        dev = torch.device("cuda", 0)
+        d_rgb = torch.full((ny * nx * 3,), 7, dtype=torch.uint8, device=dev)
+        d_acc = torch.full((ny * nx * 3,), 3.0, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        try:
+            st_n = ctx.render_device_noalloc(p, d_rgb.data_ptr(), d_acc.data_ptr())
+        except RuntimeError:
+            st_n = None
+        torch.cuda.synchronize()
+        if st_n is not None:
+            n_noalloc += 1
+            acc_n = d_acc.cpu().numpy().reshape(ny, nx, 3)
+            same = np.array_equal(np.where(np.isnan(acc_n) & np.isnan(acc), 0, acc_n.view(np.uint32)), np.where(np.isnan(acc_n) & np.isnan(acc), 0, acc.view(np.uint32)))
+            ok = same and np.array_equal(d_rgb.cpu().numpy().reshape(ny, nx, 3), rgb) and st_n["rays"] == st["rays"]
+            if not ok: tag = "NOALLOC " + tag
     if not ok:
         print("MISMATCH", tag, flush=True)
         sys.exit(1)
     n_cases += 1
     if n_cases % 20 == 0: print(n_cases, "cases", flush=True)
-print(f"{n_cases} random cases, all bit-identical to the oracle", flush=True)
+print(f"{n_cases} random cases, all bit-identical to the oracle ({n_noalloc} of them also through the entry point that allocates nothing)", flush=True)
